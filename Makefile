@@ -1,0 +1,28 @@
+# Top-level build: the HIP layer (gfx950), the C host side, and the oracle.
+# No cmake/ninja needed: hipcc + gcc + make.
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function
+LIBDIR    = sparsebench_amd/lib
+CSRC      = sparsebench_amd/csrc
+
+all: hip host oracle
+
+hip: $(LIBDIR)/libsbhip.so
+
+$(LIBDIR)/libsbhip.so: $(CSRC)/sbhip.hip $(CSRC)/kernels.hip.h include/sbhip.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/sbhip.hip -ldl
+
+host: hip
+	@if [ -f sparsebench_amd/host/Makefile ]; then $(MAKE) -C sparsebench_amd/host; fi
+
+oracle:
+	$(MAKE) -C oracle liboracle.so
+	bash oracle/build_ref.sh > /dev/null
+
+clean:
+	rm -rf $(LIBDIR) sparsebench_amd/host/build
+	$(MAKE) -C oracle clean
+
+.PHONY: all hip host oracle clean

@@ -1,0 +1,167 @@
+/* sbhip.h -- the C-ABI of the MI355X (gfx950) HIP layer for SparseBench's CG hot path.
+ *
+ * Plain C: opaque handles, pointers and sizes only.  This is what a host program
+ * written in the reference's language (C) binds; the reference-shaped symbols
+ * (convertMatrix, spMVM, waxpby, ddot, solveCG, commExchange, commReduction --
+ * see include/sparsebench/) are thin C wrappers over these entry points, and
+ * INTEGRATION.md shows the binding a SparseBench maintainer would add.
+ *
+ * Conventions (mirroring the reference):
+ *  - one process drives one GPU; all calls come from that process's main thread
+ *    (reference: src/profiler.c:17 globals, single-threaded API use);
+ *  - errors are fatal: message with file:line on stderr, then exit(EXIT_FAILURE)
+ *    (reference: src/allocate.c:19-33, src/matrix.c:129-170) -- no error codes;
+ *  - CG_FLOAT = double, CG_UINT = unsigned int (reference defaults,
+ *    src/util.h:35-53, config.mk:7-8);
+ *  - every vector pointer is a DEVICE pointer unless the name says host;
+ *  - work is enqueued on the layer's own HIP stream; calls that return a value to
+ *    the host synchronise that stream, the others do not.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * the reference root).
+ */
+#ifndef SBHIP_H
+#define SBHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sb_matrix sb_matrix; /* device-resident sparse matrix (CRS or SCS) */
+typedef struct sb_halo sb_halo;     /* device-resident halo plan of this rank     */
+typedef struct sb_cg sb_cg;         /* CG solver state (vectors + scalars in HBM) */
+
+/* ---- context ------------------------------------------------------------- */
+/* replaces: commInit's process setup, src/comm.c:863-878 (device instead of rank) */
+void sb_init(int device);
+void sb_finalize(void);
+int sb_is_initialized(void);
+int sb_device_count(void);
+const char* sb_device_name(void); /* e.g. "AMD Instinct MI355X (gfx950)" */
+int sb_num_cus(void);
+void sb_sync(void);      /* wait for the layer's stream */
+void* sb_stream(void);   /* the hipStream_t, for callers that want to order work */
+
+/* replaces: allocate(), src/allocate.h:9 -- for arrays that live on the hot path */
+void* sb_malloc(size_t bytes);
+void sb_free(void* dev);
+void sb_memset(void* dev, int byte, size_t bytes);
+void sb_h2d(void* dev, const void* host, size_t bytes); /* synchronous */
+void sb_d2h(void* host, const void* dev, size_t bytes); /* synchronous */
+void sb_d2d(void* dst, const void* src, size_t bytes);  /* stream-ordered */
+int sb_is_device_ptr(const void* p);
+
+/* stream-ordered timing (PROFILE macro, src/profiler.h:18-21, needs completion) */
+void* sb_event_create(void);
+void sb_event_record(void* ev);
+float sb_event_elapsed_ms(void* start, void* stop); /* synchronises on stop */
+void sb_event_destroy(void* ev);
+
+/* ---- matrix upload (device side of convertMatrix, src/matrix.h:57) -------- */
+/* CRS: src/CRSMatrix.h:9-16.  Arrays are host pointers, copied to HBM. */
+sb_matrix* sb_crs_upload(uint32_t nr, uint32_t nc, const uint32_t* rowPtr,
+                         const uint32_t* colInd, const double* val);
+/* Sell-C-sigma: src/SCSMatrix.h:13-27, host layout exactly as the reference's
+ * convertMatrix builds it (src/matrix-SCS.c:31-196; columns NOT permuted).
+ * For sigma > 1 the device copy of colInd is renumbered to the permuted row order
+ * (symmetric permutation) so the CG vectors can live in permuted order. */
+sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma,
+                         uint32_t nChunks, uint32_t nElems, const uint32_t* chunkPtr,
+                         const uint32_t* chunkLens, const uint32_t* colInd, const double* val,
+                         const uint32_t* oldToNewPerm, const uint32_t* newToOldPerm);
+void sb_matrix_free(sb_matrix* m);
+uint32_t sb_matrix_nr(const sb_matrix* m);
+uint32_t sb_matrix_nc(const sb_matrix* m);
+int sb_matrix_is_permuted(const sb_matrix* m); /* 1 for SCS with a non-identity row sort */
+/* algorithmic bytes one SpMV moves:
+ *   CRS 12*nnz + 4*(nr+1) + 8*nr + 8*nc ; SCS 12*nElems + 8*nChunks + 8*nrPadded + 8*nc */
+double sb_matrix_spmv_bytes(const sb_matrix* m);
+
+/* ---- kernels ---------------------------------------------------------------- */
+/* spMVM, src/solver.h:13: y = A x, x has nc entries, y has nr entries, both in
+ * the caller's (original) row order for every format and sigma. */
+void sb_spmv(const sb_matrix* m, const double* x, double* y);
+/* the SCS fast path used inside CG: x and y in the matrix's permuted row order
+ * (identical to sb_spmv when sb_matrix_is_permuted() == 0) */
+void sb_spmv_native(const sb_matrix* m, const double* x, double* y);
+/* vector <-> permuted order of an SCS matrix: out[new] = in[old] / out[old] = in[new] */
+void sb_permute(const sb_matrix* m, const double* in_orig, double* out_perm);
+void sb_unpermute(const sb_matrix* m, const double* in_perm, double* out_orig);
+
+/* waxpby, src/solver.h:15-20: w = alpha*x + beta*y (w may alias x or y) */
+void sb_waxpby(uint32_t n, double alpha, const double* x, double beta, const double* y,
+               double* w);
+/* ddot, src/solver.h:22-25 (+ commReduction SUM when a communicator is attached).
+ * Fixed summation order (DESIGN.md "dot order"): bit-reproducible run to run. */
+void sb_ddot_async(uint32_t n, const double* x, const double* y, double* result_dev);
+double sb_ddot(uint32_t n, const double* x, const double* y); /* synchronises */
+/* the two stages of the fixed order, exposed for parity tests */
+void sb_ddot_partials(uint32_t n, const double* x, const double* y, double* partials_dev);
+void sb_reduce_final(uint32_t m, const double* partials_dev, double* result_dev);
+
+/* ---- multi-GPU (one rank per GPU, RCCL over xGMI) ---------------------------- */
+/* replaces MPI_Init / MPI_COMM_WORLD.  id = 128-byte ncclUniqueId made by rank 0
+ * with sb_comm_unique_id() and handed to the other ranks by the launcher. */
+#define SB_UNIQUE_ID_BYTES 128
+void sb_comm_unique_id(void* id_out);
+void sb_comm_init(int rank, int size, const void* id);
+void sb_comm_finalize(void);
+int sb_comm_rank(void);
+int sb_comm_size(void);
+/* commReduction, src/comm.h:58 (op: 0 = MAX, 1 = SUM as enum op, src/comm.h:25);
+ * in place on one device double; stream-ordered */
+void sb_comm_reduction(double* v_dev, int op);
+/* setup-time exchanges between ranks over the same communicator, host buffers in
+ * and out (replace MPI_Allgather src/comm.c:496 and the Send/Irecv of wanted ids
+ * src/comm.c:134-161) */
+void sb_comm_allgather_bytes(const void* mine_host, int nbytes, void* all_host);
+void sb_comm_alltoallv_ints(const int* sendbuf, const int* sendcounts, const int* sdispls,
+                            int* recvbuf, const int* recvcounts, const int* rdispls);
+void sb_comm_barrier(void);
+/* device side of commPartition's result, src/comm.h:27-46: neighbour lists and
+ * elementsToSend become device arrays.  perm_of_row may be NULL (identity). */
+sb_halo* sb_halo_create(uint32_t nr, int outdegree, const int* destinations,
+                        const int* sendCounts, const int* sdispls, int indegree,
+                        const int* sources, const int* recvCounts, const int* rdispls,
+                        const int* elementsToSend, int totalSendCount, int externalCount,
+                        const uint32_t* oldToNewPerm);
+void sb_halo_free(sb_halo* h);
+/* commExchange, src/comm.h:57: pack x[elementsToSend] and deliver every
+ * neighbour's slice into x[numRows ...]; stream-ordered */
+void sb_halo_exchange(sb_halo* h, double* x);
+
+/* ---- CG (solveCG, src/solver.h:11, src/CGSolver.c:62-141) --------------------- */
+/* b_host / xexact_host: nr doubles in original row order (xexact may be NULL). */
+sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host,
+                    const double* xexact_host);
+void sb_cg_free(sb_cg* s);
+/* fused = 1: dots fused into the SpMV / update kernels; 0: the reference's op list
+ * (waxpby, spMVM, ddot as separate launches).  Same bits either way. */
+void sb_cg_set_fused(sb_cg* s, int fused);
+void sb_cg_set_graph(sb_cg* s, int use_graph);
+/* Runs solveCG's whole loop without host synchronisation; returns k exactly as
+ * the reference does (src/CGSolver.c:140).  Blocking. */
+int sb_cg_solve(sb_cg* s, int itermax, double eps);
+/* Enqueue `iters` more loop bodies (k >= 2 shape) on the stream without touching
+ * the host: what bench.py times.  sb_cg_solve(…,2,…) must have run first. */
+void sb_cg_run_iters(sb_cg* s, int iters);
+/* every r.r (index 0 = prologue) and p.Ap the solve produced, full precision */
+int sb_cg_history(const sb_cg* s, double* rr_out, int rr_cap, double* pAp_out, int pAp_cap,
+                  int* n_pAp);
+void sb_cg_solution(const sb_cg* s, double* x_host); /* original row order */
+double sb_cg_check_residual(const sb_cg* s);         /* max|x-xexact|, src/CGSolver.c:40-60 */
+/* per-region milliseconds of the last unfused solve: [waxpby, spMVM, ddot, comm]
+ * (regions of src/profiler.h:24) */
+void sb_cg_region_ms(const sb_cg* s, double out[4]);
+/* milliseconds the last solve's loop (k = 1 .. itermax-1) took on the GPU: what the
+ * reference brackets with timeStart/timeStop (src/CGSolver.c:106,130) */
+double sb_cg_loop_ms(const sb_cg* s);
+
+const char* sb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBHIP_H */

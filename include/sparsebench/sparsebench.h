@@ -1,0 +1,223 @@
+/* sparsebench.h -- the reference-shaped C API of the hot path, backed by the HIP layer.
+ *
+ * SparseBench picks its matrix format at compile time (-DCRS | -DSCS) and links
+ * exactly one matrix-<FMT>.o (reference Makefile:20,32-34; src/matrix.h:14-22):
+ * that link-time slot is its plugin boundary.  This header declares the same
+ * symbols with the same signatures, so a driver written against the reference's
+ * solver.h / matrix.h / comm.h compiles against it unchanged and links
+ * libsparsebench_<fmt>.so instead of the reference objects.
+ *
+ * Differences a caller can observe, all additive:
+ *   - Matrix gains two trailing members (`dev`, `rowNnz`) filled by convertMatrix;
+ *   - Comm always carries the halo-plan members (the reference hides them behind
+ *     _MPI) plus a trailing device handle;
+ *   - SCS: the caller's C and sigma are honoured (the reference overwrites them
+ *     with 1, src/matrix-SCS.c:42-43) and nc keeps the external columns (:38).
+ *
+ * Citations are paths in the reference tree.
+ */
+#ifndef SPARSEBENCH_H
+#define SPARSEBENCH_H
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- scalar types: src/util.h:35-53 (defaults of config.mk:7-8) --------------- */
+#ifndef CG_FLOAT
+#define CG_FLOAT double
+#endif
+#ifndef CG_UINT
+#define CG_UINT unsigned int
+#endif
+#define PRECISION_STRING "double"
+#define UINT_STRING      "unsigned int"
+#ifndef ARRAY_ALIGNMENT
+#define ARRAY_ALIGNMENT 64 /* config.mk:11 */
+#endif
+#define HLINE "----------------------------------------------------------------------\n"
+#define MAX_EXTERNAL 6000000 /* src/comm.h:16 -- kept for source compatibility only */
+
+/* ---- run-time parameters: src/parameter.h:9-18 ---------------------------------- */
+typedef struct {
+  char* filename;
+  int nx, ny, nz;
+  int itermax;
+  double eps;
+} Parameter;
+
+void initParameter(Parameter*);
+void readParameter(Parameter*, const char*);
+void printParameter(Parameter*);
+
+/* ---- general matrix + Matrix Market staging: src/matrix.h:24-49 ----------------- */
+typedef struct {
+  CG_UINT col;
+  CG_FLOAT val;
+} Entry;
+
+typedef struct {
+  CG_UINT nr, nc, nnz;
+  CG_UINT totalNr, totalNnz;
+  CG_UINT startRow, stopRow;
+  CG_UINT* rowPtr;
+  Entry* entries;
+} GMatrix;
+
+typedef struct {
+  int row;
+  int col;
+  double val;
+} MMEntry;
+
+typedef struct {
+  size_t count;
+  int nr, nnz;
+  int totalNr, totalNnz;
+  int startRow, stopRow;
+  MMEntry* entries;
+} MMMatrix;
+
+/* ---- format-specific matrices ----------------------------------------------------- */
+/* src/CRSMatrix.h:9-16 + trailing device members */
+typedef struct {
+  CG_UINT nr, nc, nnz;
+  CG_UINT totalNr, totalNnz;
+  CG_UINT startRow, stopRow;
+  CG_UINT* rowPtr;
+  CG_UINT* colInd;
+  CG_FLOAT* val;
+  void* dev;       /* sb_matrix* in HBM (include/sbhip.h) */
+  CG_UINT* rowNnz; /* nonzeros per row, for initVectors (src/CGSolver.c:27) */
+} CRSMatrix;
+
+/* src/SCSMatrix.h:13-27 + trailing device members */
+typedef struct {
+  CG_UINT nr, nc, nnz;
+  CG_UINT totalNr, totalNnz;
+  CG_UINT startRow, stopRow;
+  CG_UINT* colInd;
+  CG_FLOAT* val;
+  CG_UINT C, sigma;
+  CG_UINT nrPadded, nChunks;
+  CG_UINT nElems;
+  CG_UINT* chunkPtr;
+  CG_UINT* chunkLens;
+  CG_UINT* oldToNewPerm;
+  CG_UINT* newToOldPerm;
+  void* dev;
+  CG_UINT* rowNnz;
+} SCSMatrix;
+
+typedef struct { /* src/SCSMatrix.h:29-32 */
+  int index;
+  int count;
+} SellCSigmaPair;
+
+#if defined(CRS)
+typedef CRSMatrix Matrix;
+#define FMT "CRS"
+#elif defined(SCS)
+typedef SCSMatrix Matrix;
+#define FMT "SCS"
+#endif
+
+/* ---- communication: src/comm.h:25-46 ------------------------------------------------ */
+enum op { MAX = 0, SUM };
+
+typedef struct {
+  int rank;
+  int size;
+  FILE* logFile;
+  int externalCount;
+  int totalSendCount;
+  int* elementsToSend;
+  int indegree;
+  int outdegree;
+  int* sources;
+  int* recvCounts;
+  int* rdispls;
+  int* destinations;
+  int* sendCounts;
+  int* sdispls;
+  CG_FLOAT* sendBuffer; /* unused: packing happens in HBM */
+  void* dev;            /* sb_halo* */
+  CG_UINT* externalGlobal; /* global id of local column nr+i */
+} Comm;
+
+/* How ranks talk during SETUP (the reference uses MPI there: Allgather :496,
+ * Send/Irecv :134-161).  The launcher provides it: MPI, RCCL (sbh_exchange_rccl),
+ * torch.distributed, or nothing for one rank. */
+typedef struct {
+  void* ctx;
+  /* every rank contributes n ints; all receives size*n ints in rank order */
+  void (*allgather_ints)(void* ctx, const int* mine, int n, int* all);
+  /* rank r gets sendbuf[sdispls[r] .. +sendcounts[r]); counts are already known on
+   * both sides */
+  void (*alltoallv_ints)(void* ctx, const int* sendbuf, const int* sendcounts,
+                         const int* sdispls, int* recvbuf, const int* recvcounts,
+                         const int* rdispls);
+} sbh_exchange;
+void commSetExchange(const sbh_exchange* x); /* NULL: single rank */
+const sbh_exchange* sbh_exchange_rccl(void); /* setup exchange over the RCCL communicator */
+
+void commInit(Comm* c, int argc, char** argv);
+void commFinalize(Comm* c);
+void commDistributeMatrix(Comm* c, MMMatrix* m, MMMatrix* mLocal);
+void commPartition(Comm* c, GMatrix* m);
+void commPrintConfig(Comm* c, CG_UINT nr, CG_UINT nnz, CG_UINT startRow, CG_UINT stopRow);
+void commExchange(Comm* c, CG_UINT numRows, CG_FLOAT* x); /* x: DEVICE vector of nc entries */
+void commReduction(CG_FLOAT* v, int op);                   /* v: host or device scalar */
+void commPrintBanner(Comm* c);
+void commAbort(Comm* c, char* msg);
+static inline int commIsMaster(Comm* c) { return c->rank == 0; }
+void commBarrier(void);
+
+/* ---- setup: src/matrix.h:51-57 ----------------------------------------------------- */
+void MMMatrixRead(MMMatrix* m, char* filename);
+void matrixConvertfromMM(MMMatrix* mm, GMatrix* m);
+void matrixGenerate(GMatrix* m, Parameter* p, int rank, int size, bool use_7pt_stencil);
+void* allocate(size_t alignment, size_t bytesize); /* src/allocate.h:9 (host memory) */
+double getTimeStamp(void);                          /* src/timing.h */
+
+/* runtime-format entry points (what the drop-in symbols below forward to) */
+void sbh_convert_crs(CRSMatrix* m, GMatrix* im);
+void sbh_convert_scs(SCSMatrix* m, GMatrix* im); /* honours m->C, m->sigma set by the caller */
+void sbh_spmv(void* dev_matrix, CG_UINT nr, CG_UINT nc, const CG_FLOAT* x, CG_FLOAT* y);
+int sbh_solve_cg(Comm* comm, Parameter* param, void* dev_matrix, CG_UINT nr,
+                 const CG_UINT* rowNnz);
+
+/* ---- the hot path: src/solver.h:11-25, src/matrix.h:57 -------------------------------- */
+#if defined(CRS) || defined(SCS)
+void convertMatrix(Matrix* m, GMatrix* im);
+int solveCG(Comm* comm, Parameter* param, Matrix* m);
+/* x (nc entries) and y (nr entries) may be device or host pointers; host pointers are
+ * staged through HBM (correct, slow: use sb_malloc'ed vectors on the hot path) */
+void spMVM(Matrix* m, const CG_FLOAT* restrict x, CG_FLOAT* restrict y);
+#endif
+void waxpby(const CG_UINT n, const CG_FLOAT alpha, const CG_FLOAT* restrict x,
+            const CG_FLOAT beta, const CG_FLOAT* restrict y, CG_FLOAT* restrict w);
+void ddot(const CG_UINT n, const CG_FLOAT* restrict x, const CG_FLOAT* restrict y,
+          CG_FLOAT* restrict result);
+
+/* ---- profiler: src/profiler.h:10-30 --------------------------------------------------- */
+typedef enum { WAXPBY = 0, SPMVM, DDOT, COMM, NUMREGIONS } regions;
+extern double _t[NUMREGIONS];
+#define PROFILE(tag, call)                                                     \
+  ts = getTimeStamp();                                                         \
+  call;                                                                        \
+  sbh_profile_sync();                                                          \
+  _t[tag] += (getTimeStamp() - ts);
+void sbh_profile_sync(void); /* PROFILE needs the call complete (src/profiler.h:18-21) */
+void profilerInit(size_t* facFlops, size_t* facWords);
+void profilerPrint(Comm* c, int iterations);
+void profilerFinalize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARSEBENCH_H */

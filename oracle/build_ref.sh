@@ -1,0 +1,68 @@
+#!/usr/bin/env bash
+# build_ref.sh -- compile the REFERENCE's own hot-path sources, where they lie
+# under /root/reference/src, into oracle/_ref/ (git-ignored, travels with gpurun).
+#
+# TEST INFRASTRUCTURE ONLY.  Nothing from the reference is copied into the repo:
+# the compiler reads the sources in place and only shared objects / one binary
+# are written to oracle/_ref/.  The reference's own build system is not used
+# (its serial build fails: src/matrixBinfile.c includes mpi.h unconditionally,
+# and gcc 11 rejects -std=c23), so the files are compiled directly with ROCm
+# clang, which accepts -std=c23.  main.c and matrixBinfile.c are not on the hot
+# path and are left out of the serial libraries; oracle/ref_shim.c (ours) is the
+# caller instead.
+#
+# Outputs
+#   libsbref_crs.so       CRS, strict IEEE (-O2 -fno-fast-math -ffp-contract=off)
+#   libsbref_scs.so       SCS as-is (self-consistent for C=1 only: the reference
+#                         clobbers C and sigma, src/matrix-SCS.c:42-43)
+#   libsbref_scs_fix.so   SCS with exactly those two assignments deleted by sed
+#                         in a temp copy -- a PATCHED
+#                         reference, used only as a second opinion next to the
+#                         reference's own layout fixtures
+#   libsbref_crs_omp.so   CRS, upstream flags -O3 -ffast-math + OpenMP: the
+#                         cpu_baseline "reference" leg of bench.py (timing only)
+#   sb_ref_mpi            full reference (main.c, MPI) for multi-rank golden
+#                         histories, only if an MPI compiler wrapper is present
+set -euo pipefail
+REF=${SB_REFERENCE:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+OUT=$HERE/_ref
+S=$REF/src
+if [ ! -d "$S" ]; then
+  echo "build_ref: $S not present (expected on the GPU box) -- using prebuilt oracle/_ref" >&2
+  exit 0
+fi
+CLANG=${CLANG:-/opt/rocm/lib/llvm/bin/clang}
+mkdir -p "$OUT"
+DEFS="-DPRECISION=2 -DUINT_TYPE=1 -D_GNU_SOURCE -DARRAY_ALIGNMENT=64 -DOMP_SCHEDULE=static"
+STRICT="-O2 -fno-fast-math -ffp-contract=off -std=c23 -w -fPIC"
+COMMON="$S/CGSolver.c $S/solver.c $S/matrix.c $S/mmio.c $S/allocate.c $S/comm.c $S/bstree.c $S/timing.c $S/profiler.c $S/util.c"
+
+$CLANG -DCRS $DEFS $STRICT -I"$S" -shared -o "$OUT/libsbref_crs.so" \
+  "$HERE/ref_shim.c" $COMMON "$S/matrix-CRS.c" -Wl,--wrap=ddot -lm
+
+$CLANG -DSCS $DEFS $STRICT -I"$S" -shared -o "$OUT/libsbref_scs.so" \
+  "$HERE/ref_shim.c" $COMMON "$S/matrix-SCS.c" -Wl,--wrap=ddot -lm
+
+TMP=$(mktemp -d)
+trap 'rm -rf "$TMP"' EXIT
+sed -e '/m->C        = (CG_UINT)1;/d' -e '/m->sigma    = (CG_UINT)1;/d' "$S/matrix-SCS.c" > "$TMP/matrix-SCS-fix.c"
+$CLANG -DSCS $DEFS $STRICT -I"$S" -shared -o "$OUT/libsbref_scs_fix.so" \
+  "$HERE/ref_shim.c" $COMMON "$TMP/matrix-SCS-fix.c" -Wl,--wrap=ddot -lm
+
+# upstream optimisation flags (mk/include_CLANG.mk:15) + OpenMP, timing only
+if $CLANG -fopenmp -x c -o /dev/null -c - <<<'int main(void){return 0;}' 2>/dev/null; then
+  $CLANG -DCRS $DEFS -O3 -ffast-math -std=c23 -w -fPIC -fopenmp -I"$S" -shared \
+    -o "$OUT/libsbref_crs_omp.so" "$HERE/ref_shim.c" $COMMON "$S/matrix-CRS.c" \
+    -Wl,--wrap=ddot -lm -Wl,-rpath,/opt/rocm/lib/llvm/lib || echo "build_ref: OpenMP variant failed (non-fatal)" >&2
+fi
+
+# full MPI reference, strict, with the ddot log -> multi-rank golden histories
+MPICC=${MPICC:-/opt/conda/bin/mpicc}
+if [ -x "$MPICC" ]; then
+  MPICH_CC=$CLANG "$MPICC" -DCRS -D_MPI $DEFS -O2 -fno-fast-math -ffp-contract=off -std=c23 -w \
+    -I"$S" -o "$OUT/sb_ref_mpi" "$HERE/ref_mpi_log.c" $S/main.c $COMMON "$S/matrix-CRS.c" \
+    "$S/matrixBinfile.c" "$S/parameter.c" "$S/affinity.c" -Wl,--wrap=ddot -lm \
+    || echo "build_ref: MPI variant failed (non-fatal)" >&2
+fi
+ls -la "$OUT"

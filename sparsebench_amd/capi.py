@@ -1,0 +1,171 @@
+"""ctypes binding of the C-ABI HIP layer (include/sbhip.h -> lib/libsbhip.so).
+
+This is plumbing only: every call goes straight into the shared library.  There is
+no CPU fallback -- if the library is missing, or no MI355X is visible, using the
+hot path raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsbhip.so")
+
+# every symbol include/sbhip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "sb_init", "sb_finalize", "sb_is_initialized", "sb_device_count", "sb_device_name",
+    "sb_num_cus", "sb_sync", "sb_stream", "sb_malloc", "sb_free", "sb_memset", "sb_h2d",
+    "sb_d2h", "sb_d2d", "sb_is_device_ptr", "sb_event_create", "sb_event_record",
+    "sb_event_elapsed_ms", "sb_event_destroy", "sb_crs_upload", "sb_scs_upload",
+    "sb_matrix_free", "sb_matrix_nr", "sb_matrix_nc", "sb_matrix_is_permuted",
+    "sb_matrix_spmv_bytes", "sb_spmv", "sb_spmv_native", "sb_permute", "sb_unpermute",
+    "sb_waxpby", "sb_ddot_async", "sb_ddot", "sb_ddot_partials", "sb_reduce_final",
+    "sb_comm_unique_id", "sb_comm_init", "sb_comm_finalize", "sb_comm_rank", "sb_comm_size",
+    "sb_comm_reduction", "sb_halo_create", "sb_halo_free", "sb_halo_exchange", "sb_cg_create",
+    "sb_cg_free", "sb_cg_set_fused", "sb_cg_set_graph", "sb_cg_solve", "sb_cg_run_iters",
+    "sb_cg_history", "sb_cg_solution", "sb_cg_check_residual", "sb_cg_region_ms", "sb_version",
+    "sb_comm_allgather_bytes", "sb_comm_alltoallv_ints", "sb_comm_barrier", "sb_cg_loop_ms",
+]
+
+_lib = None
+vp = C.c_void_p
+u32 = C.c_uint32
+
+
+def load():
+    """Load libsbhip.so (no device is touched until sb_init)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "sparsebench_amd: %s is missing -- build it with `make hip` (hipcc, gfx950). "
+            "There is no CPU fallback for the hot path." % LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    sig = {
+        "sb_init": (None, [C.c_int]),
+        "sb_finalize": (None, []),
+        "sb_is_initialized": (C.c_int, []),
+        "sb_device_count": (C.c_int, []),
+        "sb_device_name": (C.c_char_p, []),
+        "sb_num_cus": (C.c_int, []),
+        "sb_sync": (None, []),
+        "sb_stream": (vp, []),
+        "sb_malloc": (vp, [C.c_size_t]),
+        "sb_free": (None, [vp]),
+        "sb_memset": (None, [vp, C.c_int, C.c_size_t]),
+        "sb_h2d": (None, [vp, vp, C.c_size_t]),
+        "sb_d2h": (None, [vp, vp, C.c_size_t]),
+        "sb_d2d": (None, [vp, vp, C.c_size_t]),
+        "sb_is_device_ptr": (C.c_int, [vp]),
+        "sb_event_create": (vp, []),
+        "sb_event_record": (None, [vp]),
+        "sb_event_elapsed_ms": (C.c_float, [vp, vp]),
+        "sb_event_destroy": (None, [vp]),
+        "sb_crs_upload": (vp, [u32, u32, vp, vp, vp]),
+        "sb_scs_upload": (vp, [u32, u32, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp]),
+        "sb_matrix_free": (None, [vp]),
+        "sb_matrix_nr": (u32, [vp]),
+        "sb_matrix_nc": (u32, [vp]),
+        "sb_matrix_is_permuted": (C.c_int, [vp]),
+        "sb_matrix_spmv_bytes": (C.c_double, [vp]),
+        "sb_spmv": (None, [vp, vp, vp]),
+        "sb_spmv_native": (None, [vp, vp, vp]),
+        "sb_permute": (None, [vp, vp, vp]),
+        "sb_unpermute": (None, [vp, vp, vp]),
+        "sb_waxpby": (None, [u32, C.c_double, vp, C.c_double, vp, vp]),
+        "sb_ddot_async": (None, [u32, vp, vp, vp]),
+        "sb_ddot": (C.c_double, [u32, vp, vp]),
+        "sb_ddot_partials": (None, [u32, vp, vp, vp]),
+        "sb_reduce_final": (None, [u32, vp, vp]),
+        "sb_comm_unique_id": (None, [vp]),
+        "sb_comm_init": (None, [C.c_int, C.c_int, vp]),
+        "sb_comm_finalize": (None, []),
+        "sb_comm_rank": (C.c_int, []),
+        "sb_comm_size": (C.c_int, []),
+        "sb_comm_reduction": (None, [vp, C.c_int]),
+        "sb_halo_create": (vp, [u32, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int,
+                                C.c_int, vp]),
+        "sb_halo_free": (None, [vp]),
+        "sb_halo_exchange": (None, [vp, vp]),
+        "sb_cg_create": (vp, [vp, vp, vp, vp]),
+        "sb_cg_free": (None, [vp]),
+        "sb_cg_set_fused": (None, [vp, C.c_int]),
+        "sb_cg_set_graph": (None, [vp, C.c_int]),
+        "sb_cg_solve": (C.c_int, [vp, C.c_int, C.c_double]),
+        "sb_cg_run_iters": (None, [vp, C.c_int]),
+        "sb_cg_history": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]),
+        "sb_cg_solution": (None, [vp, vp]),
+        "sb_cg_check_residual": (C.c_double, [vp]),
+        "sb_cg_region_ms": (None, [vp, vp]),
+        "sb_version": (C.c_char_p, []),
+        "sb_comm_allgather_bytes": (None, [vp, C.c_int, vp]),
+        "sb_comm_alltoallv_ints": (None, [vp, vp, vp, vp, vp, vp]),
+        "sb_comm_barrier": (None, []),
+        "sb_cg_loop_ms": (C.c_double, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def init(device=None):
+    """Select the GPU (LOCAL_RANK by default) and create the layer's stream."""
+    L = load()
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    if L.sb_device_count() == 0:
+        raise RuntimeError("sparsebench_amd: no HIP device visible; the HIP path is the only "
+                           "path (no CPU fallback)")
+    L.sb_init(device)
+    return L
+
+
+def _hp(a):
+    return a.ctypes.data_as(vp)
+
+
+class DeviceVector:
+    """A vector of doubles in HBM owned through the C-ABI (sb_malloc / sb_free)."""
+
+    def __init__(self, n, host=None):
+        self.L = load()
+        self.n = int(n)
+        self.ptr = self.L.sb_malloc(max(self.n, 1) * 8)
+        if host is not None:
+            self.set(host)
+
+    @classmethod
+    def from_host(cls, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return cls(len(a), a)
+
+    def set(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert len(a) == self.n
+        if self.n:
+            self.L.sb_h2d(self.ptr, _hp(a), self.n * 8)
+
+    def get(self):
+        out = np.empty(self.n, dtype=np.float64)
+        if self.n:
+            self.L.sb_d2h(_hp(out), self.ptr, self.n * 8)
+        return out
+
+    def zero(self):
+        self.L.sb_memset(self.ptr, 0, self.n * 8)
+
+    def free(self):
+        if self.ptr:
+            self.L.sb_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

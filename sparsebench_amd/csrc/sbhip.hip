@@ -1,0 +1,1063 @@
+// sbhip.hip -- implementation of the C-ABI in include/sbhip.h.
+//
+// One process drives one MI355X.  All work goes to one HIP stream; the CG loop
+// keeps alpha, beta, rtrans and the loop-exit flag in HBM so no host round trip
+// happens between iterations.  RCCL is opened lazily (dlopen) only when a
+// communicator is attached, so single-GPU runs never load it.
+#include "../../include/sbhip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "kernels.hip.h"
+
+using namespace sbk;
+
+#define HIP_CHECK(call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      fprintf(stderr, "sbhip: HIP error %s at %s:%d: %s\n", hipGetErrorName(e_), __FILE__, \
+          __LINE__, hipGetErrorString(e_));                                               \
+      exit(EXIT_FAILURE);                                                                 \
+    }                                                                                     \
+  } while (0)
+
+#define SB_FATAL(...)                                        \
+  do {                                                       \
+    fprintf(stderr, "sbhip: %s:%d: ", __FILE__, __LINE__);   \
+    fprintf(stderr, __VA_ARGS__);                            \
+    fprintf(stderr, "\n");                                   \
+    exit(EXIT_FAILURE);                                      \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// RCCL, bound at run time
+// ---------------------------------------------------------------------------
+namespace {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+enum { ncclSuccess_ = 0 };
+enum { ncclInt8_ = 0, ncclInt32_ = 2, ncclFloat64_ = 8 }; // ncclDataType_t
+enum { ncclSum_ = 0, ncclMax_ = 2 }; // ncclRedOp_t
+
+struct Rccl {
+  void* h = nullptr;
+  int (*GetUniqueId)(ncclUniqueId*);
+  int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+  int (*CommDestroy)(ncclComm_t);
+  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
+  int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t);
+  int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t);
+  int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t);
+  int (*GroupStart)();
+  int (*GroupEnd)();
+  const char* (*GetErrorString)(int);
+} rccl;
+
+void rccl_open()
+{
+  if (rccl.h) return;
+  const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+  for (const char* n : names) {
+    rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (rccl.h) break;
+  }
+  if (!rccl.h) SB_FATAL("cannot open librccl: %s", dlerror());
+#define BIND(field, sym)                                           \
+  *(void**)(&rccl.field) = dlsym(rccl.h, sym);                     \
+  if (!rccl.field) SB_FATAL("librccl lacks %s", sym)
+  BIND(GetUniqueId, "ncclGetUniqueId");
+  BIND(CommInitRank, "ncclCommInitRank");
+  BIND(CommDestroy, "ncclCommDestroy");
+  BIND(AllReduce, "ncclAllReduce");
+  BIND(AllGather, "ncclAllGather");
+  BIND(Send, "ncclSend");
+  BIND(Recv, "ncclRecv");
+  BIND(GroupStart, "ncclGroupStart");
+  BIND(GroupEnd, "ncclGroupEnd");
+  BIND(GetErrorString, "ncclGetErrorString");
+#undef BIND
+}
+#define RCCL_CHECK(call)                                                                  \
+  do {                                                                                    \
+    int r_ = (call);                                                                      \
+    if (r_ != ncclSuccess_)                                                               \
+      SB_FATAL("RCCL error %d (%s)", r_, rccl.GetErrorString ? rccl.GetErrorString(r_) : "?"); \
+  } while (0)
+
+struct Ctx {
+  bool init = false;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipDeviceProp_t prop;
+  char name[320];
+  // scratch for stand-alone ddot / permuted sb_spmv
+  double* partials = nullptr;
+  size_t partialsCap = 0;
+  double* scalar = nullptr; // one device double
+  double* ws[2] = { nullptr, nullptr };
+  size_t wsCap[2] = { 0, 0 };
+  // communicator
+  ncclComm_t comm = nullptr;
+  int rank = 0, size = 1;
+} g;
+
+void need_init()
+{
+  if (!g.init) SB_FATAL("sb_init() has not been called");
+}
+
+double* scratch_partials(size_t n)
+{
+  if (n > g.partialsCap) {
+    if (g.partials) HIP_CHECK(hipFree(g.partials));
+    g.partialsCap = n + n / 2 + 1024;
+    HIP_CHECK(hipMalloc(&g.partials, g.partialsCap * sizeof(double)));
+  }
+  return g.partials;
+}
+
+double* scratch_ws(int which, size_t n)
+{
+  if (n > g.wsCap[which]) {
+    if (g.ws[which]) HIP_CHECK(hipFree(g.ws[which]));
+    g.wsCap[which] = n;
+    HIP_CHECK(hipMalloc(&g.ws[which], n * sizeof(double)));
+  }
+  return g.ws[which];
+}
+
+inline uint32_t stream_grid(uint32_t nWork, uint32_t perBlock)
+{ // memory-bound grid: enough blocks to fill 256 CUs x 8, grid-stride the rest
+  uint32_t b   = (nWork + perBlock - 1) / perBlock;
+  uint32_t cap = (uint32_t)g.prop.multiProcessorCount * 8u;
+  if (b > cap) b = cap;
+  return b ? b : 1;
+}
+} // namespace
+
+struct sb_matrix {
+  int fmt; // 0 CRS, 1 SCS
+  uint32_t nr, nc, nnz;
+  // CRS
+  uint32_t *rowPtr = nullptr, *rowBlocks = nullptr;
+  uint32_t nRowBlocks = 0;
+  // SCS
+  uint32_t C = 0, sigma = 0, nChunks = 0, nElems = 0, nrPadded = 0;
+  uint32_t *chunkPtr = nullptr, *chunkLens = nullptr;
+  uint32_t *oldToNew = nullptr, *newToOld = nullptr; // device, nr each (SCS permuted only)
+  int permuted = 0;
+  // both
+  uint32_t* colInd = nullptr;
+  double* val = nullptr;
+};
+
+struct sb_halo {
+  uint32_t nr;
+  int outdegree, indegree, totalSend, externalCount;
+  std::vector<int> destinations, sendCounts, sdispls, sources, recvCounts, rdispls;
+  uint32_t* packIdx = nullptr; // device: row (in the vector's order) of each sent element
+  double* sendBuf = nullptr;   // device
+};
+
+struct sb_cg {
+  const sb_matrix* A;
+  sb_halo* halo;
+  uint32_t nr, nc;
+  double *r, *p, *Ap, *x, *b, *xexact;
+  CgScalars* S;
+  double* partials;
+  uint32_t nPartials;
+  double *rr_hist, *pAp_hist;
+  int hist_cap;
+  int fused, use_graph;
+  hipGraphExec_t iterGraph;
+  bool graphReady;
+  double region_ms[4];
+  std::vector<hipEvent_t> ev;
+  std::vector<int> evRegion;
+  size_t evUsed;
+  bool timing;
+  hipEvent_t evLoop0, evLoop1;
+  float loop_ms;
+};
+
+// ===========================================================================
+// context
+// ===========================================================================
+// Every sb_* function below is declared extern "C" by include/sbhip.h, which fixes
+// its linkage; the helpers in between stay C++.
+
+const char* sb_version(void) { return "sparsebench_amd sbhip 0.1 (gfx950)"; }
+
+int sb_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void sb_init(int device)
+{
+  if (g.init) {
+    if (device != g.device) SB_FATAL("already initialised on device %d", g.device);
+    return;
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0)
+    SB_FATAL("no HIP device visible (%s): the HIP path is the only path", hipGetErrorString(e));
+  if (device < 0 || device >= n) SB_FATAL("device %d out of range (%d visible)", device, n);
+  HIP_CHECK(hipSetDevice(device));
+  HIP_CHECK(hipGetDeviceProperties(&g.prop, device));
+  snprintf(g.name, sizeof g.name, "%s (%s)", g.prop.name, g.prop.gcnArchName);
+  HIP_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  HIP_CHECK(hipMalloc(&g.scalar, 64));
+  g.device = device;
+  g.init   = true;
+}
+
+void sb_finalize(void)
+{
+  if (!g.init) return;
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  if (g.comm) sb_comm_finalize();
+  if (g.partials) HIP_CHECK(hipFree(g.partials));
+  for (int i = 0; i < 2; i++)
+    if (g.ws[i]) HIP_CHECK(hipFree(g.ws[i]));
+  HIP_CHECK(hipFree(g.scalar));
+  HIP_CHECK(hipStreamDestroy(g.stream));
+  g = Ctx();
+}
+
+int sb_is_initialized(void) { return g.init ? 1 : 0; }
+const char* sb_device_name(void) { need_init(); return g.name; }
+int sb_num_cus(void) { need_init(); return g.prop.multiProcessorCount; }
+void sb_sync(void) { need_init(); HIP_CHECK(hipStreamSynchronize(g.stream)); }
+void* sb_stream(void) { need_init(); return (void*)g.stream; }
+
+void* sb_malloc(size_t bytes)
+{
+  need_init();
+  void* p = nullptr;
+  HIP_CHECK(hipMalloc(&p, bytes ? bytes : 8));
+  return p;
+}
+void sb_free(void* dev)
+{
+  if (dev) HIP_CHECK(hipFree(dev));
+}
+void sb_memset(void* dev, int byte, size_t bytes)
+{
+  need_init();
+  HIP_CHECK(hipMemsetAsync(dev, byte, bytes, g.stream));
+}
+void sb_h2d(void* dev, const void* host, size_t bytes)
+{
+  need_init();
+  HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+void sb_d2h(void* host, const void* dev, size_t bytes)
+{
+  need_init();
+  HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+void sb_d2d(void* dst, const void* src, size_t bytes)
+{
+  need_init();
+  HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g.stream));
+}
+int sb_is_device_ptr(const void* p)
+{
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return a.type == hipMemoryTypeDevice ? 1 : 0;
+}
+
+void* sb_event_create(void)
+{
+  need_init();
+  hipEvent_t e;
+  HIP_CHECK(hipEventCreate(&e));
+  return (void*)e;
+}
+void sb_event_record(void* ev) { HIP_CHECK(hipEventRecord((hipEvent_t)ev, g.stream)); }
+float sb_event_elapsed_ms(void* a, void* b)
+{
+  float ms = 0.f;
+  HIP_CHECK(hipEventSynchronize((hipEvent_t)b));
+  HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b));
+  return ms;
+}
+void sb_event_destroy(void* ev) { HIP_CHECK(hipEventDestroy((hipEvent_t)ev)); }
+
+// ===========================================================================
+// matrices
+// ===========================================================================
+static void* upload(const void* host, size_t bytes)
+{
+  void* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, bytes ? bytes : 8));
+  if (bytes) HIP_CHECK(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+  return d;
+}
+
+sb_matrix* sb_crs_upload(uint32_t nr, uint32_t nc, const uint32_t* rowPtr, const uint32_t* colInd,
+    const double* val)
+{
+  need_init();
+  sb_matrix* m = new sb_matrix();
+  m->fmt = 0, m->nr = nr, m->nc = nc, m->nnz = rowPtr[nr];
+  for (uint32_t i = 0; i < nr; i++)
+    if (rowPtr[i + 1] < rowPtr[i]) SB_FATAL("CRS rowPtr not monotone at row %u", i);
+  for (uint32_t k = 0; k < m->nnz; k++)
+    if (colInd[k] >= nc) SB_FATAL("CRS colInd[%u]=%u out of range (nc=%u)", k, colInd[k], nc);
+  // Row blocks: as many rows as fit CRS_TILE nonzeros and CRS_THREADS rows; a row
+  // longer than the tile gets a block of its own.
+  std::vector<uint32_t> rb;
+  rb.push_back(0);
+  uint32_t r = 0;
+  while (r < nr) {
+    uint32_t start = r, base = rowPtr[r];
+    while (r < nr && r - start < (uint32_t)CRS_THREADS && rowPtr[r + 1] - base <= (uint32_t)CRS_TILE) r++;
+    if (r == start) r++; // single oversize row
+    rb.push_back(r);
+  }
+  m->nRowBlocks = (uint32_t)rb.size() - 1;
+  m->rowBlocks  = (uint32_t*)upload(rb.data(), rb.size() * sizeof(uint32_t));
+  m->rowPtr     = (uint32_t*)upload(rowPtr, ((size_t)nr + 1) * sizeof(uint32_t));
+  m->colInd     = (uint32_t*)upload(colInd, (size_t)m->nnz * sizeof(uint32_t));
+  m->val        = (double*)upload(val, (size_t)m->nnz * sizeof(double));
+  return m;
+}
+
+__global__ void remap_cols_k(uint32_t n, uint32_t nr, const uint32_t* __restrict__ oldToNew,
+    uint32_t* colInd)
+{
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t c = colInd[i];
+    if (c < nr) colInd[i] = oldToNew[c];
+  }
+}
+
+sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, uint32_t nChunks,
+    uint32_t nElems, const uint32_t* chunkPtr, const uint32_t* chunkLens, const uint32_t* colInd,
+    const double* val, const uint32_t* oldToNewPerm, const uint32_t* newToOldPerm)
+{
+  need_init();
+  if (C == 0) SB_FATAL("SCS chunk height C must be >= 1");
+  if ((uint64_t)nChunks * C < nr) SB_FATAL("SCS nChunks*C < nr");
+  if (chunkPtr[nChunks] != nElems) SB_FATAL("SCS chunkPtr[nChunks] != nElems");
+  for (uint32_t c = 0; c < nChunks; c++)
+    if (chunkPtr[c + 1] - chunkPtr[c] != chunkLens[c] * C)
+      SB_FATAL("SCS chunk %u: chunkPtr/chunkLens inconsistent", c);
+  for (uint32_t k = 0; k < nElems; k++)
+    if (colInd[k] >= nc) SB_FATAL("SCS colInd[%u]=%u out of range (nc=%u)", k, colInd[k], nc);
+  sb_matrix* m = new sb_matrix();
+  m->fmt = 1, m->nr = nr, m->nc = nc, m->C = C, m->sigma = sigma, m->nChunks = nChunks;
+  m->nElems = nElems, m->nrPadded = nChunks * C, m->nnz = nElems;
+  int permuted = 0;
+  if (oldToNewPerm)
+    for (uint32_t i = 0; i < nr; i++) {
+      if (oldToNewPerm[i] >= nr) SB_FATAL("SCS oldToNewPerm[%u]=%u out of range", i, oldToNewPerm[i]);
+      if (oldToNewPerm[i] != i) permuted = 1;
+    }
+  if (permuted && !newToOldPerm) SB_FATAL("SCS permuted matrix needs newToOldPerm");
+  m->permuted  = permuted;
+  m->chunkPtr  = (uint32_t*)upload(chunkPtr, ((size_t)nChunks + 1) * sizeof(uint32_t));
+  m->chunkLens = (uint32_t*)upload(chunkLens, (size_t)nChunks * sizeof(uint32_t));
+  // +64 elements of slack so unrolled tails never touch unmapped memory
+  HIP_CHECK(hipMalloc(&m->colInd, ((size_t)nElems + 64) * sizeof(uint32_t)));
+  HIP_CHECK(hipMalloc(&m->val, ((size_t)nElems + 64) * sizeof(double)));
+  HIP_CHECK(hipMemset(m->colInd + nElems, 0, 64 * sizeof(uint32_t)));
+  HIP_CHECK(hipMemset(m->val + nElems, 0, 64 * sizeof(double)));
+  if (nElems) {
+    HIP_CHECK(hipMemcpy(m->colInd, colInd, (size_t)nElems * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(m->val, val, (size_t)nElems * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (permuted) {
+    m->oldToNew = (uint32_t*)upload(oldToNewPerm, (size_t)nr * sizeof(uint32_t));
+    m->newToOld = (uint32_t*)upload(newToOldPerm, (size_t)nr * sizeof(uint32_t));
+    hipLaunchKernelGGL(remap_cols_k, dim3(stream_grid(nElems, 256)), dim3(256), 0, g.stream, nElems,
+        nr, m->oldToNew, m->colInd);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+  }
+  return m;
+}
+
+void sb_matrix_free(sb_matrix* m)
+{
+  if (!m) return;
+  sb_free(m->rowPtr), sb_free(m->rowBlocks), sb_free(m->chunkPtr), sb_free(m->chunkLens);
+  sb_free(m->oldToNew), sb_free(m->newToOld), sb_free(m->colInd), sb_free(m->val);
+  delete m;
+}
+uint32_t sb_matrix_nr(const sb_matrix* m) { return m->nr; }
+uint32_t sb_matrix_nc(const sb_matrix* m) { return m->nc; }
+int sb_matrix_is_permuted(const sb_matrix* m) { return m->permuted; }
+double sb_matrix_spmv_bytes(const sb_matrix* m)
+{
+  if (m->fmt == 0)
+    return 12.0 * m->nnz + 4.0 * ((double)m->nr + 1) + 8.0 * m->nr + 8.0 * m->nc;
+  return 12.0 * m->nElems + 8.0 * m->nChunks + 8.0 * m->nrPadded + 8.0 * m->nc;
+}
+
+// ===========================================================================
+// kernels
+// ===========================================================================
+static int g_scs_unroll = -1;
+static int g_scs_nt     = -1;
+
+static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* dotPartials,
+    const int* stop)
+{
+  if (m->nr == 0) return;
+  if (m->fmt == 0) {
+    if (dotPartials) SB_FATAL("fused dot is an SCS C=64 feature");
+    const uint32_t per = (m->nRowBlocks + 7) / 8;
+    hipLaunchKernelGGL(spmv_crs_stream, dim3(per * 8), dim3(CRS_THREADS), 0, g.stream, m->rowBlocks,
+        m->rowPtr, m->colInd, m->val, x, y, m->nRowBlocks, per, stop);
+  } else if (m->C == 64) {
+    if (g_scs_unroll < 0) {
+      const char* u = getenv("SB_SCS_UNROLL");
+      g_scs_unroll  = u ? atoi(u) : 4;
+      const char* n = getenv("SB_SCS_NT");
+      g_scs_nt      = n ? atoi(n) : 1;
+    }
+    const uint32_t nBlocks = (m->nChunks + 3) / 4;
+    const uint32_t per     = (nBlocks + 7) / 8;
+    dim3 grid(per * 8), block(256);
+#define SCS_LAUNCH(U, D, N)                                                                      \
+  hipLaunchKernelGGL((spmv_scs64<U, D, N>), grid, block, 0, g.stream, m->chunkPtr, m->chunkLens, \
+      m->colInd, m->val, x, y, m->nr, m->nChunks, per, dotPartials, stop)
+#define SCS_PICK(U)                                                  \
+  do {                                                               \
+    if (dotPartials) { if (g_scs_nt) SCS_LAUNCH(U, true, true); else SCS_LAUNCH(U, true, false); }   \
+    else { if (g_scs_nt) SCS_LAUNCH(U, false, true); else SCS_LAUNCH(U, false, false); }             \
+  } while (0)
+    switch (g_scs_unroll) {
+    case 1: SCS_PICK(1); break;
+    case 2: SCS_PICK(2); break;
+    case 8: SCS_PICK(8); break;
+    case 9: SCS_PICK(9); break;
+    default: SCS_PICK(4); break;
+    }
+#undef SCS_PICK
+#undef SCS_LAUNCH
+  } else {
+    if (dotPartials) SB_FATAL("fused dot is an SCS C=64 feature");
+    hipLaunchKernelGGL(spmv_scs_generic, dim3((m->nrPadded + 255) / 256), dim3(256), 0, g.stream,
+        m->chunkPtr, m->chunkLens, m->colInd, m->val, x, y, m->nr, m->nrPadded, m->C, stop);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+void sb_spmv_native(const sb_matrix* m, const double* x, double* y)
+{
+  need_init();
+  launch_spmv(m, x, y, nullptr, nullptr);
+}
+
+void sb_permute(const sb_matrix* m, const double* in_orig, double* out_perm)
+{
+  need_init();
+  if (!m->permuted) {
+    if (in_orig != out_perm) sb_d2d(out_perm, in_orig, (size_t)m->nr * sizeof(double));
+    return;
+  }
+  hipLaunchKernelGGL(gather_k, dim3(stream_grid(m->nr, 256)), dim3(256), 0, g.stream, m->nr,
+      m->newToOld, in_orig, out_perm, (const int*)nullptr);
+  HIP_CHECK(hipGetLastError());
+}
+
+void sb_unpermute(const sb_matrix* m, const double* in_perm, double* out_orig)
+{
+  need_init();
+  if (!m->permuted) {
+    if (in_perm != out_orig) sb_d2d(out_orig, in_perm, (size_t)m->nr * sizeof(double));
+    return;
+  }
+  hipLaunchKernelGGL(gather_k, dim3(stream_grid(m->nr, 256)), dim3(256), 0, g.stream, m->nr,
+      m->oldToNew, in_perm, out_orig, (const int*)nullptr);
+  HIP_CHECK(hipGetLastError());
+}
+
+void sb_spmv(const sb_matrix* m, const double* x, double* y)
+{
+  need_init();
+  if (!m->permuted) {
+    launch_spmv(m, x, y, nullptr, nullptr);
+    return;
+  }
+  double* xp = scratch_ws(0, m->nc);
+  double* yp = scratch_ws(1, m->nr);
+  sb_permute(m, x, xp);
+  if (m->nc > m->nr)
+    sb_d2d(xp + m->nr, x + m->nr, (size_t)(m->nc - m->nr) * sizeof(double));
+  launch_spmv(m, xp, yp, nullptr, nullptr);
+  sb_unpermute(m, yp, y);
+}
+
+static void launch_waxpby(uint32_t n, double alpha, const double* x, double beta, const double* y,
+    double* w, const int* stop)
+{
+  if (n == 0) return;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w) & 15u) SB_FATAL("waxpby: vectors must be 16-byte aligned");
+  hipLaunchKernelGGL(waxpby_k, dim3(stream_grid(n / 2 + 1, 256)), dim3(256), 0, g.stream, n, alpha, x,
+      beta, y, w, stop);
+  HIP_CHECK(hipGetLastError());
+}
+
+void sb_waxpby(uint32_t n, double alpha, const double* x, double beta, const double* y, double* w)
+{
+  need_init();
+  launch_waxpby(n, alpha, x, beta, y, w, nullptr);
+}
+
+static void launch_dot_partials(uint32_t n, const double* x, const double* y, double* partials,
+    const int* stop)
+{
+  if (n == 0) return;
+  if (((uintptr_t)x | (uintptr_t)y) & 15u) SB_FATAL("ddot: vectors must be 16-byte aligned");
+  const uint32_t nSpans = (n + 127) / 128;
+  hipLaunchKernelGGL(ddot_partials_k, dim3(stream_grid(nSpans, 4)), dim3(256), 0, g.stream, n, x, y,
+      partials, stop);
+  HIP_CHECK(hipGetLastError());
+}
+
+void sb_ddot_partials(uint32_t n, const double* x, const double* y, double* partials_dev)
+{
+  need_init();
+  launch_dot_partials(n, x, y, partials_dev, nullptr);
+}
+
+void sb_reduce_final(uint32_t m, const double* partials_dev, double* result_dev)
+{
+  need_init();
+  hipLaunchKernelGGL(reduce_final_k, dim3(1), dim3(1024), 0, g.stream, m, partials_dev, result_dev,
+      (const int*)nullptr);
+  HIP_CHECK(hipGetLastError());
+}
+
+void sb_ddot_async(uint32_t n, const double* x, const double* y, double* result_dev)
+{
+  need_init();
+  const uint32_t m = (n + 63) / 64;
+  double* q        = scratch_partials(m);
+  launch_dot_partials(n, x, y, q, nullptr);
+  sb_reduce_final(m, q, result_dev);
+  if (g.comm) sb_comm_reduction(result_dev, 1);
+}
+
+double sb_ddot(uint32_t n, const double* x, const double* y)
+{
+  need_init();
+  sb_ddot_async(n, x, y, g.scalar);
+  double r = 0.0;
+  sb_d2h(&r, g.scalar, sizeof r);
+  return r;
+}
+
+// ===========================================================================
+// communicator + halo
+// ===========================================================================
+void sb_comm_unique_id(void* id_out)
+{
+  rccl_open();
+  ncclUniqueId id;
+  RCCL_CHECK(rccl.GetUniqueId(&id));
+  memcpy(id_out, &id, SB_UNIQUE_ID_BYTES);
+}
+
+void sb_comm_init(int rank, int size, const void* idbytes)
+{
+  need_init();
+  if (g.comm) SB_FATAL("communicator already initialised");
+  if (size < 1 || rank < 0 || rank >= size) SB_FATAL("bad rank %d / size %d", rank, size);
+  g.rank = rank, g.size = size;
+  if (size == 1) return; // serial: every comm call degrades to a no-op (src/comm.c:404-411)
+  rccl_open();
+  ncclUniqueId id;
+  memcpy(&id, idbytes, SB_UNIQUE_ID_BYTES);
+  RCCL_CHECK(rccl.CommInitRank(&g.comm, size, id, rank));
+}
+
+void sb_comm_finalize(void)
+{
+  if (g.comm) {
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    RCCL_CHECK(rccl.CommDestroy(g.comm));
+    g.comm = nullptr;
+  }
+  g.rank = 0, g.size = 1;
+}
+
+int sb_comm_rank(void) { return g.rank; }
+int sb_comm_size(void) { return g.size; }
+
+void sb_comm_reduction(double* v_dev, int op)
+{
+  need_init();
+  if (!g.comm) return;
+  RCCL_CHECK(rccl.AllReduce(v_dev, v_dev, 1, ncclFloat64_, op == 0 ? ncclMax_ : ncclSum_, g.comm,
+      g.stream));
+}
+
+void sb_comm_allgather_bytes(const void* mine_host, int nbytes, void* all_host)
+{
+  need_init();
+  if (!g.comm) {
+    memcpy(all_host, mine_host, (size_t)nbytes);
+    return;
+  }
+  char *dsend = nullptr, *drecv = nullptr;
+  HIP_CHECK(hipMalloc(&dsend, (size_t)nbytes + 8));
+  HIP_CHECK(hipMalloc(&drecv, (size_t)nbytes * g.size + 8));
+  HIP_CHECK(hipMemcpyAsync(dsend, mine_host, (size_t)nbytes, hipMemcpyHostToDevice, g.stream));
+  RCCL_CHECK(rccl.AllGather(dsend, drecv, (size_t)nbytes, ncclInt8_, g.comm, g.stream));
+  HIP_CHECK(hipMemcpyAsync(all_host, drecv, (size_t)nbytes * g.size, hipMemcpyDeviceToHost, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  HIP_CHECK(hipFree(dsend));
+  HIP_CHECK(hipFree(drecv));
+}
+
+void sb_comm_alltoallv_ints(const int* sendbuf, const int* sendcounts, const int* sdispls, int* recvbuf,
+    const int* recvcounts, const int* rdispls)
+{
+  need_init();
+  const int me = g.rank;
+  if (!g.comm) {
+    memcpy(recvbuf + rdispls[0], sendbuf + sdispls[0], (size_t)sendcounts[0] * sizeof(int));
+    return;
+  }
+  size_t ns = 0, nr = 0;
+  for (int r = 0; r < g.size; r++) {
+    if ((size_t)(sdispls[r] + sendcounts[r]) > ns) ns = (size_t)(sdispls[r] + sendcounts[r]);
+    if ((size_t)(rdispls[r] + recvcounts[r]) > nr) nr = (size_t)(rdispls[r] + recvcounts[r]);
+  }
+  int *dsend = nullptr, *drecv = nullptr;
+  HIP_CHECK(hipMalloc(&dsend, (ns + 2) * sizeof(int)));
+  HIP_CHECK(hipMalloc(&drecv, (nr + 2) * sizeof(int)));
+  HIP_CHECK(hipMemcpyAsync(dsend, sendbuf, ns * sizeof(int), hipMemcpyHostToDevice, g.stream));
+  RCCL_CHECK(rccl.GroupStart());
+  for (int r = 0; r < g.size; r++) {
+    if (r == me) continue;
+    if (sendcounts[r])
+      RCCL_CHECK(rccl.Send(dsend + sdispls[r], (size_t)sendcounts[r], ncclInt32_, r, g.comm, g.stream));
+    if (recvcounts[r])
+      RCCL_CHECK(rccl.Recv(drecv + rdispls[r], (size_t)recvcounts[r], ncclInt32_, r, g.comm, g.stream));
+  }
+  RCCL_CHECK(rccl.GroupEnd());
+  if (sendcounts[me])
+    HIP_CHECK(hipMemcpyAsync(drecv + rdispls[me], dsend + sdispls[me], (size_t)sendcounts[me] * sizeof(int),
+        hipMemcpyDeviceToDevice, g.stream));
+  HIP_CHECK(hipMemcpyAsync(recvbuf, drecv, nr * sizeof(int), hipMemcpyDeviceToHost, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  HIP_CHECK(hipFree(dsend));
+  HIP_CHECK(hipFree(drecv));
+}
+
+void sb_comm_barrier(void)
+{
+  need_init();
+  if (g.comm) {
+    HIP_CHECK(hipMemsetAsync(g.scalar, 0, sizeof(double), g.stream));
+    sb_comm_reduction(g.scalar, 1);
+  }
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+
+sb_halo* sb_halo_create(uint32_t nr, int outdegree, const int* destinations, const int* sendCounts,
+    const int* sdispls, int indegree, const int* sources, const int* recvCounts, const int* rdispls,
+    const int* elementsToSend, int totalSendCount, int externalCount, const uint32_t* oldToNewPerm)
+{
+  need_init();
+  sb_halo* h        = new sb_halo();
+  h->nr             = nr;
+  h->outdegree      = outdegree;
+  h->indegree       = indegree;
+  h->totalSend      = totalSendCount;
+  h->externalCount  = externalCount;
+  h->destinations.assign(destinations, destinations + outdegree);
+  h->sendCounts.assign(sendCounts, sendCounts + outdegree);
+  h->sdispls.assign(sdispls, sdispls + outdegree);
+  h->sources.assign(sources, sources + indegree);
+  h->recvCounts.assign(recvCounts, recvCounts + indegree);
+  h->rdispls.assign(rdispls, rdispls + indegree);
+  int sum = 0;
+  for (int i = 0; i < outdegree; i++) {
+    if (sdispls[i] != sum) SB_FATAL("halo: sdispls must be the prefix sums of sendCounts");
+    sum += sendCounts[i];
+  }
+  if (sum != totalSendCount) SB_FATAL("halo: totalSendCount mismatch");
+  sum = 0;
+  for (int i = 0; i < indegree; i++) {
+    if (rdispls[i] != sum) SB_FATAL("halo: rdispls must be the prefix sums of recvCounts");
+    sum += recvCounts[i];
+  }
+  if (sum != externalCount) SB_FATAL("halo: externalCount mismatch");
+  std::vector<uint32_t> idx((size_t)totalSendCount);
+  for (int i = 0; i < totalSendCount; i++) {
+    if (elementsToSend[i] < 0 || (uint32_t)elementsToSend[i] >= nr)
+      SB_FATAL("halo: elementsToSend[%d]=%d out of range", i, elementsToSend[i]);
+    idx[i] = oldToNewPerm ? oldToNewPerm[elementsToSend[i]] : (uint32_t)elementsToSend[i];
+  }
+  h->packIdx = (uint32_t*)upload(idx.data(), idx.size() * sizeof(uint32_t));
+  HIP_CHECK(hipMalloc(&h->sendBuf, ((size_t)totalSendCount + 1) * sizeof(double)));
+  return h;
+}
+
+void sb_halo_free(sb_halo* h)
+{
+  if (!h) return;
+  sb_free(h->packIdx), sb_free(h->sendBuf);
+  delete h;
+}
+
+static void halo_exchange(sb_halo* h, double* x, const int* stop)
+{
+  if (!h || g.size == 1) return;
+  if (h->totalSend) {
+    hipLaunchKernelGGL(gather_k, dim3(stream_grid(h->totalSend, 256)), dim3(256), 0, g.stream,
+        (uint32_t)h->totalSend, h->packIdx, x, h->sendBuf, stop);
+    HIP_CHECK(hipGetLastError());
+  }
+  // neighbour all-to-all (MPI_Neighbor_alltoallv, src/comm.c:640-648) as one
+  // RCCL group of point-to-point transfers over xGMI, received straight into the
+  // tail of x (no unpack), stream-ordered.
+  RCCL_CHECK(rccl.GroupStart());
+  for (int i = 0; i < h->outdegree; i++)
+    RCCL_CHECK(rccl.Send(h->sendBuf + h->sdispls[i], (size_t)h->sendCounts[i], ncclFloat64_,
+        h->destinations[i], g.comm, g.stream));
+  for (int i = 0; i < h->indegree; i++)
+    RCCL_CHECK(rccl.Recv(x + h->nr + h->rdispls[i], (size_t)h->recvCounts[i], ncclFloat64_,
+        h->sources[i], g.comm, g.stream));
+  RCCL_CHECK(rccl.GroupEnd());
+}
+
+void sb_halo_exchange(sb_halo* h, double* x)
+{
+  need_init();
+  halo_exchange(h, x, nullptr);
+}
+
+// ===========================================================================
+// CG
+// ===========================================================================
+enum { R_WAXPBY = 0, R_SPMVM = 1, R_DDOT = 2, R_COMM = 3 };
+
+static void mark(sb_cg* s, int region)
+{ // region = the region that ENDS here (-1: start marker)
+  if (!s->timing) return;
+  if (s->evUsed == s->ev.size()) {
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreate(&e));
+    s->ev.push_back(e);
+    s->evRegion.push_back(-1);
+  }
+  s->evRegion[s->evUsed] = region;
+  HIP_CHECK(hipEventRecord(s->ev[s->evUsed], g.stream));
+  s->evUsed++;
+}
+
+sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host, const double* xexact_host)
+{
+  need_init();
+  sb_cg* s = new sb_cg();
+  s->A = m, s->halo = halo, s->nr = m->nr, s->nc = m->nc;
+  if (halo && halo->nr != m->nr) SB_FATAL("halo plan and matrix disagree on nr");
+  if (halo && m->nr + (uint32_t)halo->externalCount != m->nc) SB_FATAL("halo externalCount != nc-nr");
+  const size_t nb = (size_t)m->nr * sizeof(double);
+  s->r  = (double*)sb_malloc(nb);
+  s->Ap = (double*)sb_malloc(nb);
+  s->x  = (double*)sb_malloc(nb);
+  s->b  = (double*)sb_malloc(nb);
+  s->p  = (double*)sb_malloc((size_t)m->nc * sizeof(double)); // nc = nr + externals (src/CGSolver.c:70)
+  s->xexact = xexact_host ? (double*)sb_malloc(nb) : nullptr;
+  double* tmp = scratch_ws(0, m->nr);
+  sb_h2d(tmp, b_host, nb);
+  sb_permute(m, tmp, s->b);
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  if (xexact_host) {
+    sb_h2d(tmp, xexact_host, nb);
+    sb_permute(m, tmp, s->xexact);
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+  }
+  s->S         = (CgScalars*)sb_malloc(sizeof(CgScalars));
+  s->nPartials = (m->nr + 63) / 64;
+  s->partials  = (double*)sb_malloc(((size_t)s->nPartials + 2) * sizeof(double));
+  s->hist_cap  = 0;
+  s->rr_hist = s->pAp_hist = nullptr;
+  s->fused      = 1;
+  s->use_graph  = 0;
+  s->graphReady = false;
+  s->iterGraph  = nullptr;
+  s->timing     = false;
+  s->evUsed     = 0;
+  s->loop_ms    = 0.f;
+  HIP_CHECK(hipEventCreate(&s->evLoop0));
+  HIP_CHECK(hipEventCreate(&s->evLoop1));
+  for (double& v : s->region_ms) v = 0.0;
+  return s;
+}
+
+void sb_cg_free(sb_cg* s)
+{
+  if (!s) return;
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  if (s->iterGraph) HIP_CHECK(hipGraphExecDestroy(s->iterGraph));
+  for (hipEvent_t e : s->ev) HIP_CHECK(hipEventDestroy(e));
+  HIP_CHECK(hipEventDestroy(s->evLoop0));
+  HIP_CHECK(hipEventDestroy(s->evLoop1));
+  sb_free(s->r), sb_free(s->Ap), sb_free(s->x), sb_free(s->b), sb_free(s->p), sb_free(s->xexact);
+  sb_free(s->S), sb_free(s->partials), sb_free(s->rr_hist), sb_free(s->pAp_hist);
+  delete s;
+}
+
+void sb_cg_set_fused(sb_cg* s, int fused)
+{
+  if (s->fused != fused && s->iterGraph) {
+    HIP_CHECK(hipGraphExecDestroy(s->iterGraph));
+    s->iterGraph = nullptr, s->graphReady = false;
+  }
+  s->fused = fused;
+}
+void sb_cg_set_graph(sb_cg* s, int use_graph) { s->use_graph = use_graph; }
+
+static bool can_fuse_dot(const sb_cg* s) { return s->fused && s->A->fmt == 1 && s->A->C == 64; }
+
+// r.r / p.Ap epilogue: partials -> (all-reduce) -> scalar update, all on device
+template <int MODE> static void scalar_step(sb_cg* s, double eps)
+{
+  const bool multi = g.comm != nullptr;
+  if (!multi) {
+    hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials,
+        s->partials, s->S, eps, s->rr_hist, s->pAp_hist, s->hist_cap, 0);
+  } else {
+    hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials,
+        s->partials, s->S, eps, s->rr_hist, s->pAp_hist, s->hist_cap, 1);
+    mark(s, R_DDOT);
+    sb_comm_reduction(&s->S->local, 1);
+    mark(s, R_COMM);
+    hipLaunchKernelGGL((cg_scalar_k<MODE, false>), dim3(1), dim3(1024), 0, g.stream, s->nPartials,
+        s->partials, s->S, eps, s->rr_hist, s->pAp_hist, s->hist_cap, 0);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+static void spmv_and_dot(sb_cg* s, double eps)
+{ // COMM: halo ; SPMVM: Ap = A p ; DDOT: p.Ap -> alpha   (src/CGSolver.c:122-126)
+  const int* stop = &s->S->stop;
+  halo_exchange(s->halo, s->p, stop);
+  mark(s, R_COMM);
+  if (can_fuse_dot(s)) {
+    launch_spmv(s->A, s->p, s->Ap, s->partials, stop);
+    mark(s, R_SPMVM);
+  } else {
+    launch_spmv(s->A, s->p, s->Ap, nullptr, stop);
+    mark(s, R_SPMVM);
+    launch_dot_partials(s->nr, s->p, s->Ap, s->partials, stop);
+  }
+  scalar_step<2>(s, eps);
+  mark(s, R_DDOT);
+}
+
+static void update_x_r(sb_cg* s)
+{ // x += alpha p ; r -= alpha Ap (+ partials of the next r.r)   (:127-128, :112)
+  const uint32_t n = s->nr;
+  if (s->fused) {
+    hipLaunchKernelGGL(cg_update_xr_dot, dim3(stream_grid((n + 127) / 128, 4)), dim3(256), 0, g.stream, n,
+        s->x, s->p, s->r, s->Ap, s->S, s->partials);
+    HIP_CHECK(hipGetLastError());
+    mark(s, R_WAXPBY);
+  } else {
+    // the reference's two waxpby calls; alpha / -alpha come from the control block
+    dim3 gridV(stream_grid(n / 2 + 1, 256)), blockV(256);
+    hipLaunchKernelGGL(waxpby_sdev_k, gridV, blockV, 0, g.stream, n, s->x, &s->S->alpha, s->p, s->x,
+        &s->S->stop);
+    hipLaunchKernelGGL(waxpby_sdev_k, gridV, blockV, 0, g.stream, n, s->r, &s->S->neg_alpha, s->Ap,
+        s->r, &s->S->stop);
+    HIP_CHECK(hipGetLastError());
+    mark(s, R_WAXPBY);
+  }
+}
+
+static void loop_body(sb_cg* s, int k, double eps)
+{
+  const uint32_t n = s->nr;
+  dim3 gridV(stream_grid(n / 2 + 1, 256)), blockV(256);
+  if (k == 1) {
+    hipLaunchKernelGGL(cg_iter1_begin, dim3(1), dim3(1), 0, g.stream, s->S);
+    hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, s->S, 1);
+    HIP_CHECK(hipGetLastError());
+    mark(s, R_WAXPBY);
+  } else {
+    if (!s->fused) launch_dot_partials(n, s->r, s->r, s->partials, &s->S->stop);
+    scalar_step<1>(s, eps);
+    mark(s, R_DDOT);
+    hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, s->S, 0);
+    HIP_CHECK(hipGetLastError());
+    mark(s, R_WAXPBY);
+  }
+  spmv_and_dot(s, eps);
+  update_x_r(s);
+}
+
+static void ensure_hist(sb_cg* s, int cap)
+{
+  if (cap <= s->hist_cap) return;
+  sb_free(s->rr_hist), sb_free(s->pAp_hist);
+  s->hist_cap = cap;
+  s->rr_hist  = (double*)sb_malloc((size_t)cap * sizeof(double));
+  s->pAp_hist = (double*)sb_malloc((size_t)cap * sizeof(double));
+  if (s->iterGraph) { // captured pointers are stale
+    HIP_CHECK(hipGraphExecDestroy(s->iterGraph));
+    s->iterGraph = nullptr, s->graphReady = false;
+  }
+}
+
+static void run_body_maybe_graph(sb_cg* s, double eps)
+{ // k >= 2 bodies are iteration-invariant (k lives in the device control block)
+  if (!s->use_graph || g.comm || s->timing) {
+    loop_body(s, 2, eps);
+    return;
+  }
+  if (!s->graphReady) {
+    hipGraph_t graph;
+    HIP_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+    loop_body(s, 2, eps);
+    HIP_CHECK(hipStreamEndCapture(g.stream, &graph));
+    HIP_CHECK(hipGraphInstantiate(&s->iterGraph, graph, nullptr, nullptr, 0));
+    HIP_CHECK(hipGraphDestroy(graph));
+    s->graphReady = true;
+  }
+  HIP_CHECK(hipGraphLaunch(s->iterGraph, g.stream));
+}
+
+static double g_last_eps = 0.0;
+
+int sb_cg_solve(sb_cg* s, int itermax, double eps)
+{
+  need_init();
+  const uint32_t n = s->nr;
+  ensure_hist(s, itermax + 2);
+  g_last_eps = eps;
+  s->timing  = !s->fused; // the reference-shaped op list is the one that gets the region table
+  s->evUsed  = 0;
+  HIP_CHECK(hipMemsetAsync(s->S, 0, sizeof(CgScalars), g.stream));
+  HIP_CHECK(hipMemsetAsync(s->x, 0, (size_t)n * sizeof(double), g.stream));   // x0 = 0 (:28)
+  HIP_CHECK(hipMemsetAsync(s->p, 0, (size_t)s->nc * sizeof(double), g.stream));
+  mark(s, -1);
+  // prologue, src/CGSolver.c:94-100
+  launch_waxpby(n, 1.0, s->x, 0.0, s->x, s->p, nullptr);
+  mark(s, R_WAXPBY);
+  halo_exchange(s->halo, s->p, nullptr);
+  mark(s, R_COMM);
+  launch_spmv(s->A, s->p, s->Ap, nullptr, nullptr);
+  mark(s, R_SPMVM);
+  if (n && s->fused) {
+    hipLaunchKernelGGL(cg_residual_dot, dim3(stream_grid((n + 127) / 128, 4)), dim3(256), 0, g.stream, n,
+        s->b, s->Ap, s->r, s->partials);
+    HIP_CHECK(hipGetLastError());
+    mark(s, R_WAXPBY);
+  } else if (n) {
+    launch_waxpby(n, 1.0, s->b, -1.0, s->Ap, s->r, nullptr);
+    mark(s, R_WAXPBY);
+    launch_dot_partials(n, s->r, s->r, s->partials, nullptr);
+  }
+  scalar_step<0>(s, eps);
+  mark(s, R_DDOT);
+  HIP_CHECK(hipEventRecord(s->evLoop0, g.stream));
+  for (int k = 1; k < itermax; k++) {
+    if (k == 1) loop_body(s, 1, eps);
+    else run_body_maybe_graph(s, eps);
+  }
+  HIP_CHECK(hipEventRecord(s->evLoop1, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  HIP_CHECK(hipEventElapsedTime(&s->loop_ms, s->evLoop0, s->evLoop1));
+  CgScalars h;
+  HIP_CHECK(hipMemcpy(&h, s->S, sizeof h, hipMemcpyDeviceToHost));
+  if (s->timing) {
+    for (double& v : s->region_ms) v = 0.0;
+    for (size_t i = 1; i < s->evUsed; i++) {
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, s->ev[i - 1], s->ev[i]));
+      if (s->evRegion[i] >= 0) s->region_ms[s->evRegion[i]] += ms;
+    }
+  }
+  s->timing = false;
+  return h.iters + 1; // the value of k when the reference's for loop exits (:107,:140)
+}
+
+void sb_cg_run_iters(sb_cg* s, int iters)
+{
+  need_init();
+  for (int i = 0; i < iters; i++) run_body_maybe_graph(s, g_last_eps);
+}
+
+int sb_cg_history(const sb_cg* s, double* rr_out, int rr_cap, double* pAp_out, int pAp_cap, int* n_pAp)
+{
+  need_init();
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  CgScalars h;
+  HIP_CHECK(hipMemcpy(&h, s->S, sizeof h, hipMemcpyDeviceToHost));
+  int nrr = h.n_rr < s->hist_cap ? h.n_rr : s->hist_cap;
+  int npa = h.n_pAp < s->hist_cap ? h.n_pAp : s->hist_cap;
+  if (nrr > rr_cap) nrr = rr_cap;
+  if (npa > pAp_cap) npa = pAp_cap;
+  if (nrr > 0) HIP_CHECK(hipMemcpy(rr_out, s->rr_hist, (size_t)nrr * sizeof(double), hipMemcpyDeviceToHost));
+  if (npa > 0) HIP_CHECK(hipMemcpy(pAp_out, s->pAp_hist, (size_t)npa * sizeof(double), hipMemcpyDeviceToHost));
+  if (n_pAp) *n_pAp = npa;
+  return nrr;
+}
+
+void sb_cg_solution(const sb_cg* s, double* x_host)
+{
+  need_init();
+  double* tmp = scratch_ws(1, s->nr);
+  sb_unpermute(s->A, s->x, tmp);
+  sb_d2h(x_host, tmp, (size_t)s->nr * sizeof(double));
+}
+
+double sb_cg_check_residual(const sb_cg* s)
+{
+  need_init();
+  if (!s->xexact || s->nr == 0) return 0.0;
+  const uint32_t blocks = stream_grid(s->nr, 256);
+  double* q             = scratch_partials(blocks);
+  hipLaunchKernelGGL(max_abs_diff_partials, dim3(blocks), dim3(256), 0, g.stream, s->nr, s->x, s->xexact, q);
+  HIP_CHECK(hipGetLastError());
+  std::vector<double> h(blocks);
+  sb_d2h(h.data(), q, blocks * sizeof(double));
+  double m = 0.0;
+  for (double v : h)
+    if (v > m) m = v;
+  if (g.comm) { // commReduction(&residual, MAX), src/CGSolver.c:55
+    sb_h2d(g.scalar, &m, sizeof m);
+    sb_comm_reduction(g.scalar, 0);
+    sb_d2h(&m, g.scalar, sizeof m);
+  }
+  return m;
+}
+
+double sb_cg_loop_ms(const sb_cg* s) { return (double)s->loop_ms; }
+
+void sb_cg_region_ms(const sb_cg* s, double out[4])
+{
+  for (int i = 0; i < 4; i++) out[i] = s->region_ms[i];
+}
+

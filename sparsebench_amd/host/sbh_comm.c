@@ -1,0 +1,371 @@
+/* sbh_comm.c -- rank bootstrap, 1-D block-row partition with halo plan, and the
+ * run-time halo / reduction calls, for one rank per GPU.
+ *
+ * What it replaces in the reference: commInit/commFinalize (src/comm.c:863-905),
+ * commDistributeMatrix (:311-412), commPartition (:414-625) with its helpers
+ * buildIndexMapping (:40-114) and buildElementsToSend (:116-182), commExchange
+ * (:627-651), commReduction (:653-662).  The reference talks MPI everywhere; here
+ * setup traffic goes through the launcher-provided sbh_exchange (RCCL by default),
+ * and the per-iteration traffic is RCCL over xGMI inside the HIP layer.
+ */
+#define _GNU_SOURCE
+#include <stdlib.h>
+#include <unistd.h>
+
+#include "sbhip.h"
+#include "sparsebench/sparsebench.h"
+
+static const sbh_exchange* g_xchg = NULL;
+
+void commSetExchange(const sbh_exchange* x) { g_xchg = x; }
+
+/* ---- setup exchange over RCCL --------------------------------------------------- */
+static void rccl_allgather(void* ctx, const int* mine, int n, int* all)
+{
+  (void)ctx;
+  sb_comm_allgather_bytes(mine, n * (int)sizeof(int), all);
+}
+static void rccl_alltoallv(void* ctx, const int* sendbuf, const int* sendcounts, const int* sdispls,
+    int* recvbuf, const int* recvcounts, const int* rdispls)
+{
+  (void)ctx;
+  sb_comm_alltoallv_ints(sendbuf, sendcounts, sdispls, recvbuf, recvcounts, rdispls);
+}
+static const sbh_exchange g_rccl_exchange = { NULL, rccl_allgather, rccl_alltoallv };
+const sbh_exchange* sbh_exchange_rccl(void) { return &g_rccl_exchange; }
+
+/* ---- bootstrap --------------------------------------------------------------------- */
+static int env_int(const char* const* names, int dflt)
+{
+  for (; *names; names++) {
+    const char* v = getenv(*names);
+    if (v && *v) return atoi(v);
+  }
+  return dflt;
+}
+
+/* One process per GPU.  Rank and size come from the launcher's environment
+ * (torchrun: RANK/WORLD_SIZE/LOCAL_RANK; mpiexec.hydra used as a plain process
+ * launcher: PMI_RANK/PMI_SIZE; or SB_RANK/SB_SIZE).  The RCCL unique id travels
+ * through a file in /tmp that rank 0 publishes atomically. */
+void commInit(Comm* c, int argc, char** argv)
+{
+  (void)argc, (void)argv;
+  static const char* const rankNames[]  = { "SB_RANK", "RANK", "PMI_RANK", "OMPI_COMM_WORLD_RANK", NULL };
+  static const char* const sizeNames[]  = { "SB_SIZE", "WORLD_SIZE", "PMI_SIZE", "OMPI_COMM_WORLD_SIZE", NULL };
+  static const char* const localNames[] = { "SB_LOCAL_RANK", "LOCAL_RANK", "MPI_LOCALRANKID",
+    "OMPI_COMM_WORLD_LOCAL_RANK", NULL };
+  memset(c, 0, sizeof *c);
+  c->rank    = env_int(rankNames, 0);
+  c->size    = env_int(sizeNames, 1);
+  c->logFile = NULL;
+  int ndev   = sb_device_count();
+  if (ndev <= 0) {
+    fprintf(stderr, "sparsebench: no HIP device visible; there is no CPU fallback\n");
+    exit(EXIT_FAILURE);
+  }
+  int local = env_int(localNames, c->rank % ndev);
+  sb_init(local % ndev);
+  if (c->size > 1) {
+    unsigned char id[SB_UNIQUE_ID_BYTES];
+    char path[512], tmp[544];
+    const char* f = getenv("SB_ID_FILE");
+    const char* port = getenv("MASTER_PORT");
+    if (f) snprintf(path, sizeof path, "%s", f);
+    else snprintf(path, sizeof path, "/tmp/sbhip_id_%s_%d", port ? port : "0", (int)getppid());
+    if (c->rank == 0) {
+      sb_comm_unique_id(id);
+      snprintf(tmp, sizeof tmp, "%s.tmp", path);
+      FILE* o = fopen(tmp, "wb");
+      if (!o || fwrite(id, 1, sizeof id, o) != sizeof id) {
+        fprintf(stderr, "sparsebench: cannot write %s\n", tmp);
+        exit(EXIT_FAILURE);
+      }
+      fclose(o);
+      rename(tmp, path);
+    } else {
+      FILE* i = NULL;
+      for (int tries = 0; tries < 6000 && !(i = fopen(path, "rb")); tries++) usleep(10000);
+      if (!i || fread(id, 1, sizeof id, i) != sizeof id) {
+        fprintf(stderr, "sparsebench: rank %d could not read the RCCL id from %s\n", c->rank, path);
+        exit(EXIT_FAILURE);
+      }
+      fclose(i);
+    }
+    sb_comm_init(c->rank, c->size, id);
+    sb_comm_barrier();
+    if (c->rank == 0) unlink(path);
+    commSetExchange(sbh_exchange_rccl());
+  }
+}
+
+void commFinalize(Comm* c)
+{
+  if (c->dev) sb_halo_free((sb_halo*)c->dev);
+  c->dev = NULL;
+  free(c->elementsToSend), free(c->sources), free(c->recvCounts), free(c->rdispls);
+  free(c->destinations), free(c->sendCounts), free(c->sdispls), free(c->externalGlobal);
+  c->elementsToSend = c->sources = c->recvCounts = c->rdispls = NULL;
+  c->destinations = c->sendCounts = c->sdispls = NULL;
+  c->externalGlobal = NULL;
+  sb_finalize();
+}
+
+void commBarrier(void)
+{
+  if (sb_is_initialized()) sb_comm_barrier();
+}
+
+void commAbort(Comm* c, char* msg)
+{ /* src/comm.c:880-891: message from the master, then a clean exit */
+  if (commIsMaster(c)) printf("%s\n", msg);
+  if (sb_is_initialized()) sb_finalize();
+  exit(EXIT_SUCCESS);
+}
+
+void commPrintBanner(Comm* c)
+{
+  if (!commIsMaster(c)) return;
+  printf(HLINE);
+  printf("SparseBench CG hot path -- MI355X HIP build (%s)\n", sb_version());
+  printf("Device: %s, %d CUs\n", sb_device_name(), sb_num_cus());
+#ifdef FMT
+  printf("Using %s matrix format, %s precision floats and integer type %s\n", FMT, PRECISION_STRING,
+      UINT_STRING);
+#else
+  printf("Using %s precision floats and integer type %s\n", PRECISION_STRING, UINT_STRING);
+#endif
+  if (c->size > 1) printf("RCCL parallel using %d ranks (one per GPU)\n", c->size);
+  else printf("Running with only one process!\n");
+  printf(HLINE);
+}
+
+void commPrintConfig(Comm* c, CG_UINT nr, CG_UINT nnz, CG_UINT startRow, CG_UINT stopRow)
+{
+  printf("Rank %d of %d: %u rows (%u..%u), %u nonzeros, %d externals, %d to send, "
+         "%d in-neighbours, %d out-neighbours\n",
+      c->rank, c->size, nr, startRow, stopRow, nnz, c->externalCount, c->totalSendCount, c->indegree,
+      c->outdegree);
+}
+
+/* ---- row split of file matrices: src/comm.c:35-38, :347-361 -------------------------- */
+static void rows_of_rank(int rank, int size, int N, int* first, int* last)
+{
+  int base = N / size, extra = N % size;
+  *first = rank * base + (rank < extra ? rank : extra);
+  *last  = *first + base + (rank < extra ? 1 : 0) - 1;
+}
+
+/* Every rank has read the file (MMMatrixRead) -- there is no scatter; a rank keeps
+ * the entries of its own row range.  One rank: alias, as src/comm.c:404-411. */
+void commDistributeMatrix(Comm* c, MMMatrix* m, MMMatrix* mLocal)
+{
+  int first, last;
+  rows_of_rank(c->rank, c->size, m->nr, &first, &last);
+  if (commIsMaster(c) && c->size > 1)
+    for (int r = 0; r < c->size; r++) {
+      int a, b;
+      rows_of_rank(r, c->size, m->nr, &a, &b);
+      printf("Rank %d start %d stop %d\n", r, a, b);
+    }
+  size_t lo = 0, hi = m->count;
+  if (c->size > 1) {
+    while (lo < m->count && m->entries[lo].row < first) lo++;
+    hi = lo;
+    while (hi < m->count && m->entries[hi].row <= last) hi++;
+  }
+  mLocal->entries  = m->entries + lo;
+  mLocal->count    = hi - lo;
+  mLocal->nnz      = (int)(hi - lo);
+  mLocal->startRow = first;
+  mLocal->stopRow  = last;
+  mLocal->nr       = last - first + 1;
+  mLocal->totalNr  = m->nr;
+  mLocal->totalNnz = m->nnz;
+}
+
+/* ---- partition + halo plan --------------------------------------------------------- */
+typedef struct {
+  CG_UINT* keys;
+  int* vals;
+  size_t cap, used;
+} idmap;
+
+static size_t slot_of(const idmap* h, CG_UINT k)
+{
+  size_t i = ((size_t)k * 0x9E3779B1u) & (h->cap - 1);
+  while (h->vals[i] >= 0 && h->keys[i] != k) i = (i + 1) & (h->cap - 1);
+  return i;
+}
+
+static void idmap_init(idmap* h, size_t cap)
+{
+  h->cap  = cap;
+  h->used = 0;
+  h->keys = (CG_UINT*)malloc(cap * sizeof(CG_UINT));
+  h->vals = (int*)malloc(cap * sizeof(int));
+  for (size_t i = 0; i < cap; i++) h->vals[i] = -1;
+}
+
+static void idmap_grow(idmap* h)
+{
+  idmap n;
+  idmap_init(&n, h->cap * 4);
+  for (size_t i = 0; i < h->cap; i++)
+    if (h->vals[i] >= 0) {
+      size_t s  = slot_of(&n, h->keys[i]);
+      n.keys[s] = h->keys[i], n.vals[s] = h->vals[i];
+    }
+  n.used = h->used;
+  free(h->keys), free(h->vals);
+  *h = n;
+}
+
+void commPartition(Comm* c, GMatrix* A)
+{
+  c->externalCount = c->totalSendCount = c->indegree = c->outdegree = 0;
+  if (c->size == 1) return; /* serial build of the reference: no-op (src/comm.c:416,624) */
+  if (!g_xchg) {
+    fprintf(stderr, "commPartition: %d ranks but no setup exchange installed (commSetExchange)\n", c->size);
+    exit(EXIT_FAILURE);
+  }
+  const int P      = c->size;
+  const CG_UINT nr = A->nr, first = A->startRow, last = A->stopRow;
+
+  /* 1. external columns in first-seen order (src/comm.c:452-473; hash instead of BST) */
+  idmap seen;
+  idmap_init(&seen, 1u << 12);
+  size_t extCap  = 1024;
+  CG_UINT* extId = (CG_UINT*)malloc(extCap * sizeof(CG_UINT));
+  int nExt       = 0;
+  for (CG_UINT i = 0; i < nr; i++)
+    for (CG_UINT j = A->rowPtr[i]; j < A->rowPtr[i + 1]; j++) {
+      const CG_UINT g = A->entries[j].col;
+      if (g >= first && g <= last) continue;
+      size_t s = slot_of(&seen, g);
+      if (seen.vals[s] >= 0) continue;
+      seen.keys[s] = g, seen.vals[s] = nExt, seen.used++;
+      if ((size_t)nExt == extCap) extId = (CG_UINT*)realloc(extId, (extCap *= 2) * sizeof(CG_UINT));
+      extId[nExt++] = g;
+      if (seen.used * 2 > seen.cap) idmap_grow(&seen);
+    }
+
+  /* 2. owners (src/comm.c:496-520): last rank whose first row <= id */
+  int* starts = (int*)malloc((size_t)P * sizeof(int));
+  int mine    = (int)first;
+  g_xchg->allgather_ints(g_xchg->ctx, &mine, 1, starts);
+  int* owner = (int*)malloc(((size_t)nExt + 1) * sizeof(int));
+  int* want  = (int*)calloc((size_t)P, sizeof(int)); /* want[s]: how many ids I need from s */
+  for (int i = 0; i < nExt; i++) {
+    int lo = 0, hi = P - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) / 2;
+      if ((CG_UINT)starts[mid] <= extId[i]) lo = mid;
+      else hi = mid - 1;
+    }
+    owner[i] = lo;
+    want[lo]++;
+  }
+
+  /* 3. local numbering (src/comm.c:60-110): externals follow the nr local columns,
+   * grouped by owner -- ascending owner, which is the order the receive displacements
+   * assume -- and first-seen inside a group */
+  int* base = (int*)malloc(((size_t)P + 1) * sizeof(int));
+  base[0]   = 0;
+  for (int s = 0; s < P; s++) base[s + 1] = base[s] + want[s];
+  int* fill         = (int*)calloc((size_t)P, sizeof(int));
+  int* localOf      = (int*)malloc(((size_t)nExt + 1) * sizeof(int));
+  c->externalGlobal = (CG_UINT*)malloc(((size_t)nExt + 1) * sizeof(CG_UINT));
+  for (int i = 0; i < nExt; i++) {
+    int pos                = base[owner[i]] + fill[owner[i]]++;
+    localOf[i]             = (int)nr + pos;
+    c->externalGlobal[pos] = extId[i];
+  }
+  for (CG_UINT i = 0; i < nr; i++)
+    for (CG_UINT j = A->rowPtr[i]; j < A->rowPtr[i + 1]; j++) {
+      const CG_UINT g = A->entries[j].col;
+      if (g >= first && g <= last) A->entries[j].col = g - first;
+      else A->entries[j].col = (CG_UINT)localOf[seen.vals[slot_of(&seen, g)]];
+    }
+  A->nc            = A->nc + (CG_UINT)nExt; /* src/comm.c:616 */
+  c->externalCount = nExt;
+
+  c->sources    = (int*)malloc(((size_t)P + 1) * sizeof(int));
+  c->recvCounts = (int*)malloc(((size_t)P + 1) * sizeof(int));
+  c->rdispls    = (int*)malloc(((size_t)P + 1) * sizeof(int));
+  for (int s = 0; s < P; s++)
+    if (want[s] > 0) {
+      c->sources[c->indegree]    = s;
+      c->recvCounts[c->indegree] = want[s];
+      c->rdispls[c->indegree]    = base[s];
+      c->indegree++;
+    }
+
+  /* 4. tell every owner which of its rows I need (src/comm.c:116-166): the counts
+   * matrix by all-gather, the id lists by all-to-all */
+  int* wantAll = (int*)malloc((size_t)P * P * sizeof(int)); /* wantAll[d*P+s] */
+  g_xchg->allgather_ints(g_xchg->ctx, want, P, wantAll);
+  int* give     = (int*)malloc((size_t)P * sizeof(int)); /* give[d]: ids rank d needs from me */
+  int* giveDisp = (int*)malloc(((size_t)P + 1) * sizeof(int));
+  giveDisp[0]   = 0;
+  for (int d = 0; d < P; d++) {
+    give[d]         = wantAll[(size_t)d * P + c->rank];
+    giveDisp[d + 1] = giveDisp[d] + give[d];
+  }
+  c->totalSendCount = giveDisp[P];
+  c->elementsToSend = (int*)malloc(((size_t)c->totalSendCount + 1) * sizeof(int));
+  g_xchg->alltoallv_ints(g_xchg->ctx, (const int*)c->externalGlobal, want, base, c->elementsToSend,
+      give, giveDisp);
+  for (int i = 0; i < c->totalSendCount; i++) c->elementsToSend[i] -= (int)first;
+
+  c->destinations = (int*)malloc(((size_t)P + 1) * sizeof(int));
+  c->sendCounts   = (int*)malloc(((size_t)P + 1) * sizeof(int));
+  c->sdispls      = (int*)malloc(((size_t)P + 1) * sizeof(int));
+  for (int d = 0; d < P; d++)
+    if (give[d] > 0) {
+      c->destinations[c->outdegree] = d;
+      c->sendCounts[c->outdegree]   = give[d];
+      c->sdispls[c->outdegree]      = giveDisp[d];
+      c->outdegree++;
+    }
+
+  free(seen.keys), free(seen.vals), free(extId), free(starts), free(owner), free(want);
+  free(base), free(fill), free(localOf), free(wantAll), free(give), free(giveDisp);
+}
+
+/* ---- run time ------------------------------------------------------------------------- */
+void sbh_comm_attach_halo(Comm* c, CG_UINT nr, const CG_UINT* oldToNewPerm)
+{
+  if (c->dev) sb_halo_free((sb_halo*)c->dev);
+  c->dev = NULL;
+  if (c->size == 1) return;
+  c->dev = sb_halo_create(nr, c->outdegree, c->destinations, c->sendCounts, c->sdispls, c->indegree,
+      c->sources, c->recvCounts, c->rdispls, c->elementsToSend, c->totalSendCount, c->externalCount,
+      oldToNewPerm);
+}
+
+/* x: device vector with nc = numRows + externalCount entries */
+void commExchange(Comm* c, CG_UINT numRows, CG_FLOAT* x)
+{
+  if (c->size == 1) return;
+  if (!c->dev) sbh_comm_attach_halo(c, numRows, NULL);
+  if (!sb_is_device_ptr(x)) {
+    fprintf(stderr, "commExchange: x must live in HBM (sb_malloc) when running on %d ranks\n", c->size);
+    exit(EXIT_FAILURE);
+  }
+  sb_halo_exchange((sb_halo*)c->dev, x);
+}
+
+void commReduction(CG_FLOAT* v, int op)
+{
+  if (!sb_is_initialized() || sb_comm_size() == 1) return;
+  if (sb_is_device_ptr(v)) {
+    sb_comm_reduction(v, op);
+    return;
+  }
+  double* d = (double*)sb_malloc(sizeof(double));
+  sb_h2d(d, v, sizeof(double));
+  sb_comm_reduction(d, op);
+  sb_d2h(v, d, sizeof(double));
+  sb_free(d);
+}

@@ -1,0 +1,198 @@
+/* sbh_solver.c -- the C side of the solver API: solveCG, spMVM, waxpby, ddot with the
+ * reference's signatures (src/solver.h:11-25), each a thin call into the HIP layer.
+ * Also the profiler table (src/profiler.c) because solveCG feeds it.
+ *
+ * Pointer convention: hot-path vectors live in HBM (sb_malloc).  A host pointer is
+ * accepted everywhere the reference's own driver passes one (src/main.c:205-215
+ * allocates x, y with allocate()): it is staged through HBM -- still computed on the
+ * GPU, just slower.  Nothing here computes on the CPU.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdlib.h>
+
+#include "sbhip.h"
+#include "sparsebench/sparsebench.h"
+
+void sbh_comm_attach_halo(Comm* c, CG_UINT nr, const CG_UINT* oldToNewPerm);
+
+double _t[NUMREGIONS];
+
+void sbh_profile_sync(void)
+{
+  if (sb_is_initialized()) sb_sync();
+}
+
+/* ---- staging helpers --------------------------------------------------------------- */
+typedef struct {
+  const void* host;
+  double* dev;
+  int staged;
+} staged_vec;
+
+static staged_vec stage_in(const double* p, size_t n, int copy)
+{
+  staged_vec s = { p, (double*)p, 0 };
+  if (n == 0 || sb_is_device_ptr(p)) return s;
+  s.dev    = (double*)sb_malloc(n * sizeof(double));
+  s.staged = 1;
+  if (copy) sb_h2d(s.dev, p, n * sizeof(double));
+  return s;
+}
+
+static void stage_out(staged_vec* s, double* host, size_t n)
+{
+  if (!s->staged) return;
+  if (host) sb_d2h(host, s->dev, n * sizeof(double));
+  sb_free(s->dev);
+}
+
+/* ---- kernels with the reference's names ---------------------------------------------- */
+void waxpby(const CG_UINT n, const CG_FLOAT alpha, const CG_FLOAT* restrict x, const CG_FLOAT beta,
+    const CG_FLOAT* restrict y, CG_FLOAT* restrict w)
+{
+  staged_vec sx = stage_in(x, n, 1);
+  staged_vec sy = (y == x) ? sx : stage_in(y, n, 1);
+  staged_vec sw = (w == x) ? sx : (w == y) ? sy : stage_in(w, n, 0);
+  sb_waxpby(n, alpha, sx.dev, beta, sy.dev, sw.dev);
+  if (sw.staged) sb_d2h(w, sw.dev, (size_t)n * sizeof(double));
+  if (sw.staged && w != x && w != y) sb_free(sw.dev);
+  if (sy.staged && y != x) sb_free(sy.dev);
+  if (sx.staged) sb_free(sx.dev);
+}
+
+void ddot(const CG_UINT n, const CG_FLOAT* restrict x, const CG_FLOAT* restrict y,
+    CG_FLOAT* restrict result)
+{
+  staged_vec sx = stage_in(x, n, 1);
+  staged_vec sy = (y == x) ? sx : stage_in(y, n, 1);
+  *result       = sb_ddot(n, sx.dev, sy.dev); /* includes the SUM all-reduce (src/solver.c:60) */
+  if (sy.staged && y != x) sb_free(sy.dev);
+  if (sx.staged) sb_free(sx.dev);
+}
+
+void sbh_spmv(void* dev_matrix, CG_UINT nr, CG_UINT nc, const CG_FLOAT* x, CG_FLOAT* y)
+{
+  staged_vec sx = stage_in(x, nc, 1);
+  staged_vec sy = stage_in(y, nr, 0);
+  sb_spmv((const sb_matrix*)dev_matrix, sx.dev, sy.dev);
+  stage_out(&sy, y, nr);
+  stage_out(&sx, NULL, nc);
+}
+
+/* ---- solveCG --------------------------------------------------------------------------- */
+/* src/CGSolver.c:62-141.  The whole loop runs in the HIP layer without host round
+ * trips; the lines the reference prints while iterating are printed afterwards from
+ * the recorded history (same text, same order). */
+static int sbh_solve(Comm* comm, Parameter* param, void* dev_matrix, CG_UINT nr, const CG_UINT* rowNnz,
+    const CG_UINT* oldToNewPerm)
+{
+  const int itermax    = param->itermax;
+  const int generated  = strcmp(param->filename, "generate") == 0 || strcmp(param->filename, "generate7P") == 0;
+  double* b            = (double*)allocate(ARRAY_ALIGNMENT, ((size_t)nr + 1) * sizeof(double));
+  double* xexact       = generated ? (double*)allocate(ARRAY_ALIGNMENT, ((size_t)nr + 1) * sizeof(double)) : NULL;
+  /* initVectors, src/CGSolver.c:25-36 */
+  for (CG_UINT i = 0; i < nr; i++) {
+    if (generated) {
+      b[i]      = 27.0 - ((double)((int)rowNnz[i] - 1));
+      xexact[i] = 1.0;
+    } else {
+      b[i] = 1.0;
+    }
+  }
+  sbh_comm_attach_halo(comm, nr, oldToNewPerm);
+  sb_cg* cg = sb_cg_create((const sb_matrix*)dev_matrix, (sb_halo*)comm->dev, b, xexact);
+  const char* fused = getenv("SB_FUSED");
+  const char* graph = getenv("SB_GRAPH");
+  if (fused) sb_cg_set_fused(cg, atoi(fused));
+  if (graph) sb_cg_set_graph(cg, atoi(graph));
+
+  const int k = sb_cg_solve(cg, itermax, param->eps);
+
+  const int cap = itermax + 2;
+  double* rr    = (double*)malloc((size_t)cap * sizeof(double));
+  double* pAp   = (double*)malloc((size_t)cap * sizeof(double));
+  int nPAp      = 0;
+  const int nRr = sb_cg_history(cg, rr, cap, pAp, cap, &nPAp);
+  int printFreq = itermax / 10; /* :85-91 */
+  if (printFreq > 50) printFreq = 50;
+  if (printFreq < 1) printFreq = 1;
+  if (commIsMaster(comm)) {
+    printf("Initial Residual = %E\n", nRr > 0 ? sqrt(rr[0]) : 0.0);
+    /* iteration j's residual is sqrt of the r.r entering it: rr[0] for j = 1, rr[j-1] after */
+    for (int j = 1; j < k; j++)
+      if (j % printFreq == 0 || j + 1 == itermax) {
+        const int idx = j == 1 ? 0 : j - 1;
+        if (idx < nRr) printf("Iteration = %d Residual = %E\n", j, sqrt(rr[idx]));
+      }
+    printf("Solution performed %d iterations and took %.2fs\n", k, 1e-3 * sb_cg_loop_ms(cg));
+  }
+  /* solverCheckResidual, :40-60 */
+  if (xexact) {
+    const double diff = sb_cg_check_residual(cg);
+    if (commIsMaster(comm)) printf("Difference between computed and exact  = %f\n", diff);
+  }
+  double ms[4];
+  sb_cg_region_ms(cg, ms);
+  double sum = ms[0] + ms[1] + ms[2] + ms[3];
+  if (sum > 0.0) {
+    _t[WAXPBY] += 1e-3 * ms[0], _t[SPMVM] += 1e-3 * ms[1], _t[DDOT] += 1e-3 * ms[2], _t[COMM] += 1e-3 * ms[3];
+  } else {
+    /* fused run: regions overlap inside kernels; attribute the loop to the SpMV row so
+     * the table still adds up (run with SB_FUSED=0 for the per-region split) */
+    _t[SPMVM] += 1e-3 * sb_cg_loop_ms(cg);
+  }
+  sb_cg_free(cg);
+  free(rr), free(pAp), free(b), free(xexact);
+  return k;
+}
+
+int sbh_solve_cg(Comm* comm, Parameter* param, void* dev_matrix, CG_UINT nr, const CG_UINT* rowNnz)
+{
+  return sbh_solve(comm, param, dev_matrix, nr, rowNnz, NULL);
+}
+
+int sbh_solve_cg_perm(Comm* comm, Parameter* param, void* dev_matrix, CG_UINT nr, const CG_UINT* rowNnz,
+    const CG_UINT* oldToNewPerm)
+{
+  return sbh_solve(comm, param, dev_matrix, nr, rowNnz, oldToNewPerm);
+}
+
+/* ---- profiler table: src/profiler.c:11-141 ----------------------------------------------- */
+static const char* const kLabel[NUMREGIONS] = { "waxpby:  ", "spMVM:   ", "ddot:    ", "comm:    " };
+static double g_words[NUMREGIONS], g_flops[NUMREGIONS];
+
+void profilerInit(size_t* facFlops, size_t* facWords)
+{
+  /* per-iteration work: waxpby 3 words / 6 flops per row-factor, ddot 2 / 4, spMVM words
+   * given whole and 2 flops per nonzero (src/profiler.c:19-22,35-41) */
+  static const double w[NUMREGIONS] = { 3, 0, 2, 0 }, fl[NUMREGIONS] = { 6, 2, 4, 0 };
+  for (int i = 0; i < NUMREGIONS; i++) {
+    _t[i]      = 0.0;
+    g_words[i] = w[i] * (double)facWords[i];
+    g_flops[i] = fl[i] * (double)facFlops[i];
+  }
+  g_words[SPMVM] = (double)facWords[SPMVM];
+  g_words[COMM] = g_flops[COMM] = 0.0;
+}
+
+void profilerPrint(Comm* c, int iterations)
+{
+  if (!commIsMaster(c)) return;
+  printf(HLINE);
+  if (c->size > 1) printf("Function   Rate(MB/s)  Rate(MFlop/s)  Walltime(s)   [rank 0 of %d]\n", c->size);
+  else printf("Function   Rate(MB/s)  Rate(MFlop/s)  Walltime(s)\n");
+  for (int j = 0; j < NUMREGIONS - 1; j++) {
+    const double t = _t[j] > 0.0 ? _t[j] : 1e-30;
+    printf("%s%11.2f %11.2f %11.2f\n", kLabel[j], 1.0E-06 * g_words[j] * iterations / t,
+        1.0E-06 * g_flops[j] * iterations / t, _t[j]);
+  }
+  printf(HLINE);
+  if (c->size > 1) {
+    const double kB = 1.0E-03 * sizeof(CG_FLOAT) * (double)(c->totalSendCount + c->externalCount);
+    printf("Communication (rank 0): %.2f kB per exchange, %.2e s in comm\n", kB, _t[COMM]);
+    printf(HLINE);
+  }
+}
+
+void profilerFinalize(void) {}

@@ -1,0 +1,190 @@
+"""Python mirror of the C host side (libsparsebench_host.so) for tests and bench.py.
+
+`Problem` sequences what the C driver does -- matrixGenerate | MMMatrixRead ->
+commPartition -> convertMatrix -- through the flat surface in host/sbh_flat.c, and
+`CG` wraps the HIP layer's solveCG (sb_cg_*).  Plumbing only: no arithmetic happens in
+Python, and nothing here falls back to the CPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB = os.path.join(HERE, "lib", "libsparsebench_host.so")
+vp = C.c_void_p
+_host = None
+
+# setup-exchange callbacks (include/sparsebench/sparsebench.h: sbh_exchange)
+ALLGATHER_FN = C.CFUNCTYPE(None, vp, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int))
+ALLTOALLV_FN = C.CFUNCTYPE(None, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                           C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
+
+
+class ExchangeS(C.Structure):
+    _fields_ = [("ctx", vp), ("allgather_ints", ALLGATHER_FN), ("alltoallv_ints", ALLTOALLV_FN)]
+
+
+def host():
+    global _host
+    if _host is not None:
+        return _host
+    capi.load()  # libsbhip.so first (RTLD_GLOBAL): the host library links against it
+    if not os.path.exists(HOST_LIB):
+        raise RuntimeError("sparsebench_amd: %s is missing -- run `make host`" % HOST_LIB)
+    H = C.CDLL(HOST_LIB, mode=C.RTLD_GLOBAL)
+    H.sbh_problem_create.restype = vp
+    H.sbh_problem_create.argtypes = [C.c_char_p] + [C.c_int] * 9
+    H.sbh_problem_matrix.restype = vp
+    H.sbh_problem_matrix.argtypes = [vp]
+    H.sbh_problem_halo.restype = vp
+    H.sbh_problem_halo.argtypes = [vp]
+    H.sbh_problem_setup_seconds.restype = C.c_double
+    H.sbh_problem_setup_seconds.argtypes = [vp]
+    H.sbh_problem_scalar.restype = C.c_uint
+    H.sbh_problem_scalar.argtypes = [vp, C.c_int]
+    H.sbh_problem_array.restype = vp
+    H.sbh_problem_array.argtypes = [vp, C.c_int]
+    H.sbh_problem_values.restype = vp
+    H.sbh_problem_values.argtypes = [vp]
+    H.sbh_problem_gm_entries.argtypes = [vp, vp, vp]
+    H.sbh_problem_rhs.restype = C.c_int
+    H.sbh_problem_rhs.argtypes = [vp, vp, vp]
+    H.sbh_problem_free.argtypes = [vp]
+    H.commSetExchange.argtypes = [vp]
+    H.sbh_exchange_rccl.restype = vp
+    _host = H
+    return H
+
+
+_SCALARS = ["nr", "nc", "nnz", "nnzTrue", "totalNr", "totalNnz", "startRow", "stopRow", "C",
+            "sigma", "nChunks", "nrPadded", "nElems", "externalCount", "totalSendCount",
+            "indegree", "outdegree"]
+_ARRAYS = {"rowPtr": 0, "rowNnz": 1, "crs_colInd": 2, "chunkPtr": 3, "chunkLens": 4,
+           "scs_colInd": 5, "oldToNewPerm": 6, "newToOldPerm": 7, "elementsToSend": 8,
+           "sources": 9, "recvCounts": 10, "rdispls": 11, "destinations": 12, "sendCounts": 13,
+           "sdispls": 14, "externalGlobal": 15}
+
+
+def _view(ptr, n, dtype):
+    if not ptr or n == 0:
+        return np.zeros(0, dtype=dtype)
+    ct = {np.uint32: C.c_uint32, np.int32: C.c_int32, np.float64: C.c_double}[dtype]
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(int(n),))
+
+
+class Problem:
+    """One rank's matrix: generated HPCG stencil or a .mtx file, partitioned, converted
+    and (upload=True) resident in HBM."""
+
+    def __init__(self, filename="generate", nx=16, ny=16, nz=16, fmt="scs", Cc=64, sigma=1,
+                 rank=0, size=1, upload=True):
+        self.H = host()
+        self.fmt = fmt
+        self.upload = upload
+        self.ptr = self.H.sbh_problem_create(os.fsencode(filename), nx, ny, nz,
+                                             0 if fmt == "crs" else 1, Cc, sigma, rank, size,
+                                             1 if upload else 0)
+        for i, name in enumerate(_SCALARS):
+            setattr(self, name, int(self.H.sbh_problem_scalar(self.ptr, i)))
+
+    def array(self, name):
+        n = {"rowPtr": self.nr + 1, "rowNnz": self.nr, "crs_colInd": self.nnzTrue,
+             "chunkPtr": self.nChunks + 1, "chunkLens": self.nChunks, "scs_colInd": self.nElems,
+             "oldToNewPerm": self.nr, "newToOldPerm": self.nr,
+             "elementsToSend": self.totalSendCount, "sources": self.indegree,
+             "recvCounts": self.indegree, "rdispls": self.indegree,
+             "destinations": self.outdegree, "sendCounts": self.outdegree,
+             "sdispls": self.outdegree, "externalGlobal": self.externalCount}[name]
+        dt = np.int32 if name in ("elementsToSend", "sources", "recvCounts", "rdispls",
+                                  "destinations", "sendCounts", "sdispls") else np.uint32
+        return _view(self.H.sbh_problem_array(self.ptr, _ARRAYS[name]), n, dt)
+
+    def values(self):
+        n = self.nnzTrue if self.fmt == "crs" else self.nElems
+        return _view(self.H.sbh_problem_values(self.ptr), n, np.float64)
+
+    def gm_entries(self):
+        col = np.empty(self.nnzTrue, dtype=np.uint32)
+        val = np.empty(self.nnzTrue, dtype=np.float64)
+        self.H.sbh_problem_gm_entries(self.ptr, col.ctypes.data_as(vp), val.ctypes.data_as(vp))
+        return col, val
+
+    def rhs(self):
+        b = np.empty(self.nr)
+        xe = np.empty(self.nr)
+        gen = self.H.sbh_problem_rhs(self.ptr, b.ctypes.data_as(vp), xe.ctypes.data_as(vp))
+        return b, (xe if gen else None)
+
+    @property
+    def matrix(self):
+        return self.H.sbh_problem_matrix(self.ptr)
+
+    @property
+    def halo(self):
+        return self.H.sbh_problem_halo(self.ptr)
+
+    @property
+    def setup_seconds(self):
+        return self.H.sbh_problem_setup_seconds(self.ptr)
+
+    def spmv_bytes(self):
+        return capi.load().sb_matrix_spmv_bytes(self.matrix)
+
+    def free(self):
+        if self.ptr:
+            self.H.sbh_problem_free(self.ptr)
+            self.ptr = None
+
+
+class CG:
+    """solveCG on the GPU (sb_cg_*): state in HBM, loop without host round trips."""
+
+    def __init__(self, problem, fused=True, graph=False):
+        self.L = capi.load()
+        self.problem = problem
+        b, xe = problem.rhs()
+        self.ptr = self.L.sb_cg_create(problem.matrix, problem.halo, b.ctypes.data_as(vp),
+                                       xe.ctypes.data_as(vp) if xe is not None else None)
+        self.L.sb_cg_set_fused(self.ptr, int(fused))
+        self.L.sb_cg_set_graph(self.ptr, int(graph))
+        self.itermax = 0
+
+    def solve(self, itermax=150, eps=0.0):
+        self.itermax = itermax
+        return self.L.sb_cg_solve(self.ptr, itermax, eps)
+
+    def run_iters(self, iters):
+        self.L.sb_cg_run_iters(self.ptr, iters)
+
+    def history(self):
+        cap = self.itermax + 2
+        rr = np.zeros(cap)
+        pap = np.zeros(cap)
+        npap = C.c_int(0)
+        nrr = self.L.sb_cg_history(self.ptr, rr.ctypes.data_as(vp), cap, pap.ctypes.data_as(vp),
+                                   cap, C.byref(npap))
+        return rr[:nrr].copy(), pap[:npap.value].copy()
+
+    def solution(self):
+        x = np.empty(self.problem.nr)
+        self.L.sb_cg_solution(self.ptr, x.ctypes.data_as(vp))
+        return x
+
+    def check_residual(self):
+        return self.L.sb_cg_check_residual(self.ptr)
+
+    def loop_ms(self):
+        return self.L.sb_cg_loop_ms(self.ptr)
+
+    def region_ms(self):
+        out = np.zeros(4)
+        self.L.sb_cg_region_ms(self.ptr, out.ctypes.data_as(vp))
+        return dict(zip(["waxpby", "spMVM", "ddot", "comm"], out))
+
+    def free(self):
+        if self.ptr:
+            self.L.sb_cg_free(self.ptr)
+            self.ptr = None
