@@ -159,6 +159,18 @@ void sb_cg_region_ms(const sb_cg* s, double out[4]);
  * reference brackets with timeStart/timeStop (src/CGSolver.c:106,130) */
 double sb_cg_loop_ms(const sb_cg* s);
 
+/* bench instrumentation: bracket every SpMV launch of the loop with HIP events on the
+ * layer's stream; sb_cg_spmv_ms returns their summed duration and count */
+void sb_cg_spmv_timing(sb_cg* s, int on);
+double sb_cg_spmv_ms(sb_cg* s, int* launches);
+/* device control block: out = {stop, stop_next, iters, n_rr, n_pAp} (proof that the
+ * timed iterations really ran) */
+void sb_cg_counters(const sb_cg* s, int out[5]);
+
+/* debug/measurement: raw streaming-read rate of the device in GB/s (DESIGN.md uses it
+ * as the measured ceiling next to the 8 TB/s spec) */
+double sb_debug_stream_read_gbs(size_t bytes, int reps);
+
 const char* sb_version(void);
 
 #ifdef __cplusplus

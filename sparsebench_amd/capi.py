@@ -26,6 +26,7 @@ SYMBOLS = [
     "sb_cg_free", "sb_cg_set_fused", "sb_cg_set_graph", "sb_cg_solve", "sb_cg_run_iters",
     "sb_cg_history", "sb_cg_solution", "sb_cg_check_residual", "sb_cg_region_ms", "sb_version",
     "sb_comm_allgather_bytes", "sb_comm_alltoallv_ints", "sb_comm_barrier", "sb_cg_loop_ms",
+    "sb_cg_spmv_timing", "sb_cg_spmv_ms", "sb_cg_counters", "sb_debug_stream_read_gbs",
 ]
 
 _lib = None
@@ -104,6 +105,10 @@ def load():
         "sb_comm_alltoallv_ints": (None, [vp, vp, vp, vp, vp, vp]),
         "sb_comm_barrier": (None, []),
         "sb_cg_loop_ms": (C.c_double, [vp]),
+        "sb_cg_spmv_timing": (None, [vp, C.c_int]),
+        "sb_cg_spmv_ms": (C.c_double, [vp, C.POINTER(C.c_int)]),
+        "sb_cg_counters": (None, [vp, vp]),
+        "sb_debug_stream_read_gbs": (C.c_double, [C.c_size_t, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

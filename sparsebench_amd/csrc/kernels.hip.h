@@ -82,13 +82,14 @@ __global__ __launch_bounds__(256) void spmv_scs64(const uint32_t* __restrict__ c
     uint32_t nr, uint32_t nChunks, uint32_t blocksPerXcd, double* __restrict__ dotPartials,
     const int* __restrict__ stop)
 {
-  if (stop && *stop) return;
-  const uint32_t lb    = xcd_block(blockIdx.x, blocksPerXcd);
+  const int stopped    = stop ? *stop : 0; // one wait covers this and the loads below
+  const uint32_t lb    = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
   const uint32_t chunk = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
   const uint32_t lane  = threadIdx.x & 63u;
   if (chunk >= nChunks) return;
   const uint32_t cp  = chunkPtr[chunk];
   const uint32_t len = chunkLens[chunk];
+  if (stopped) return;
   const double* v    = val + cp + lane;
   const uint32_t* c  = colInd + cp + lane;
   double acc         = 0.0;
@@ -111,6 +112,66 @@ __global__ __launch_bounds__(256) void spmv_scs64(const uint32_t* __restrict__ c
     double vv   = NT ? stream_load(v + (size_t)j * 64) : v[(size_t)j * 64];
     uint32_t cc = NT ? stream_load(c + (size_t)j * 64) : c[(size_t)j * 64];
     acc         = acc + vv * x[cc];
+  }
+  const uint32_t row = chunk * 64u + lane;
+  if (row < nr) y[row] = acc;
+  if (DOT) {
+    double t = row < nr ? x[row] * acc : 0.0;
+    t        = butterfly64(t);
+    if (lane == 0) dotPartials[chunk] = t;
+  }
+}
+
+// Software-pipelined form of the same kernel.  A wave streams its chunk in batches of
+// U columns; the val/colInd loads of batch b+1 are issued right after the x-gathers
+// of batch b, so the HBM latency of the stream overlaps the L2 latency of the gather
+// instead of adding to it.  Loads may run up to U-1 columns past the chunk's end (the
+// arrays carry SCS_SLACK elements of zero padding, and a following chunk's indices
+// are valid columns); such columns are never accumulated.  Same per-row order, same
+// bits as spmv_scs64.
+constexpr uint32_t SCS_SLACK = 16 * 64;
+
+template <int U, bool DOT>
+__global__ __launch_bounds__(256) void spmv_scs64_pipe(const uint32_t* __restrict__ chunkPtr,
+    const uint32_t* __restrict__ chunkLens, const uint32_t* __restrict__ colInd,
+    const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
+    uint32_t nr, uint32_t nChunks, uint32_t blocksPerXcd, double* __restrict__ dotPartials,
+    const int* __restrict__ stop)
+{
+  const int stopped    = stop ? *stop : 0; // issued together with the loads below
+  const uint32_t lb    = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
+  const uint32_t chunk = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
+  const uint32_t lane  = threadIdx.x & 63u;
+  if (chunk >= nChunks) return;
+  const uint32_t cp  = chunkPtr[chunk];
+  const uint32_t len = chunkLens[chunk];
+  if (stopped) return;
+  const double* v   = val + cp + lane;
+  const uint32_t* c = colInd + cp + lane;
+  double acc        = 0.0;
+  double va[U], vb[U];
+  uint32_t ca[U], cb[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    va[u] = stream_load(v + (size_t)u * 64);
+    ca[u] = stream_load(c + (size_t)u * 64);
+  }
+  for (uint32_t j = 0; j < len; j += U) {
+    double xx[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) xx[u] = x[ca[u]];
+    if (j + U < len) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        vb[u] = stream_load(v + (size_t)(j + U + u) * 64);
+        cb[u] = stream_load(c + (size_t)(j + U + u) * 64);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (j + u < len) acc = acc + va[u] * xx[u];
+#pragma unroll
+    for (int u = 0; u < U; u++) va[u] = vb[u], ca[u] = cb[u];
   }
   const uint32_t row = chunk * 64u + lane;
   if (row < nr) y[row] = acc;
@@ -371,8 +432,18 @@ __global__ __launch_bounds__(256) void cg_residual_dot(uint32_t n, const double*
 __device__ __forceinline__ double reduce_final_block(uint32_t m, const double* __restrict__ q,
     double* lds16)
 {
-  double s = 0.0;
-  for (uint32_t i = threadIdx.x; i < m; i += 1024u) s = s + q[i];
+  double s   = 0.0;
+  uint32_t i = threadIdx.x;
+  // same order as the plain loop, but 8 independent loads are in flight at a time
+  // (the partials were written by other CUs: every load is an L2/fabric round trip)
+  for (; i + 7u * 1024u < m; i += 8u * 1024u) {
+    double a[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] = q[i + (uint32_t)u * 1024u];
+#pragma unroll
+    for (int u = 0; u < 8; u++) s = s + a[u];
+  }
+  for (; i < m; i += 1024u) s = s + q[i];
   s = butterfly64(s);
   if ((threadIdx.x & 63u) == 0) lds16[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -489,6 +560,19 @@ __global__ __launch_bounds__(256) void max_abs_diff_partials(uint32_t n,
       if (w[i] > m) m = w[i];
     out[blockIdx.x] = m;
   }
+}
+
+// debug: pure streaming read (16 B per lane), result folded so nothing is elided
+__global__ __launch_bounds__(256) void stream_read_k(const double2* __restrict__ in, size_t n2,
+    double* __restrict__ out)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  double acc          = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    const double2 v = in[i];
+    acc += v.x + v.y;
+  }
+  if (acc == 123.456) out[0] = acc;
 }
 
 } // namespace sbk

@@ -187,6 +187,10 @@ struct sb_cg {
   bool timing;
   hipEvent_t evLoop0, evLoop1;
   float loop_ms;
+  // optional in-situ timing of every SpMV launch (bench.py's roofline leg)
+  bool spmvTiming;
+  std::vector<hipEvent_t> spmvEv;
+  size_t spmvEvUsed;
 };
 
 // ===========================================================================
@@ -217,7 +221,7 @@ void sb_init(int device)
   if (device < 0 || device >= n) SB_FATAL("device %d out of range (%d visible)", device, n);
   HIP_CHECK(hipSetDevice(device));
   HIP_CHECK(hipGetDeviceProperties(&g.prop, device));
-  snprintf(g.name, sizeof g.name, "%s (%s)", g.prop.name, g.prop.gcnArchName);
+  snprintf(g.name, sizeof g.name, "%s (%s)", g.prop.name[0] ? g.prop.name : "AMD Instinct", g.prop.gcnArchName);
   HIP_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
   HIP_CHECK(hipMalloc(&g.scalar, 64));
   g.device = device;
@@ -379,11 +383,12 @@ sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, u
   m->permuted  = permuted;
   m->chunkPtr  = (uint32_t*)upload(chunkPtr, ((size_t)nChunks + 1) * sizeof(uint32_t));
   m->chunkLens = (uint32_t*)upload(chunkLens, (size_t)nChunks * sizeof(uint32_t));
-  // +64 elements of slack so unrolled tails never touch unmapped memory
-  HIP_CHECK(hipMalloc(&m->colInd, ((size_t)nElems + 64) * sizeof(uint32_t)));
-  HIP_CHECK(hipMalloc(&m->val, ((size_t)nElems + 64) * sizeof(double)));
-  HIP_CHECK(hipMemset(m->colInd + nElems, 0, 64 * sizeof(uint32_t)));
-  HIP_CHECK(hipMemset(m->val + nElems, 0, 64 * sizeof(double)));
+  // SCS_SLACK zeroed elements behind the data: the pipelined kernel prefetches up to
+  // U-1 columns past a chunk's end
+  HIP_CHECK(hipMalloc(&m->colInd, ((size_t)nElems + SCS_SLACK) * sizeof(uint32_t)));
+  HIP_CHECK(hipMalloc(&m->val, ((size_t)nElems + SCS_SLACK) * sizeof(double)));
+  HIP_CHECK(hipMemset(m->colInd + nElems, 0, SCS_SLACK * sizeof(uint32_t)));
+  HIP_CHECK(hipMemset(m->val + nElems, 0, SCS_SLACK * sizeof(double)));
   if (nElems) {
     HIP_CHECK(hipMemcpy(m->colInd, colInd, (size_t)nElems * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(m->val, val, (size_t)nElems * sizeof(double), hipMemcpyHostToDevice));
@@ -421,6 +426,8 @@ double sb_matrix_spmv_bytes(const sb_matrix* m)
 // ===========================================================================
 static int g_scs_unroll = -1;
 static int g_scs_nt     = -1;
+static int g_scs_xcd    = 1;
+static int g_scs_pipe   = 0;
 
 static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* dotPartials,
     const int* stop)
@@ -437,10 +444,14 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
       g_scs_unroll  = u ? atoi(u) : 4;
       const char* n = getenv("SB_SCS_NT");
       g_scs_nt      = n ? atoi(n) : 1;
+      const char* xc = getenv("SB_SCS_XCD");
+      g_scs_xcd     = xc ? atoi(xc) : 1;
+      const char* pp = getenv("SB_SCS_PIPE");
+      g_scs_pipe    = pp ? atoi(pp) : 0;
     }
     const uint32_t nBlocks = (m->nChunks + 3) / 4;
-    const uint32_t per     = (nBlocks + 7) / 8;
-    dim3 grid(per * 8), block(256);
+    const uint32_t per     = g_scs_xcd ? (nBlocks + 7) / 8 : 0;
+    dim3 grid(g_scs_xcd ? per * 8 : nBlocks), block(256);
 #define SCS_LAUNCH(U, D, N)                                                                      \
   hipLaunchKernelGGL((spmv_scs64<U, D, N>), grid, block, 0, g.stream, m->chunkPtr, m->chunkLens, \
       m->colInd, m->val, x, y, m->nr, m->nChunks, per, dotPartials, stop)
@@ -449,13 +460,36 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
     if (dotPartials) { if (g_scs_nt) SCS_LAUNCH(U, true, true); else SCS_LAUNCH(U, true, false); }   \
     else { if (g_scs_nt) SCS_LAUNCH(U, false, true); else SCS_LAUNCH(U, false, false); }             \
   } while (0)
+#define PIPE_LAUNCH(U, D)                                                                        \
+  hipLaunchKernelGGL((spmv_scs64_pipe<U, D>), grid, block, 0, g.stream, m->chunkPtr, m->chunkLens, \
+      m->colInd, m->val, x, y, m->nr, m->nChunks, per, dotPartials, stop)
+#define PIPE_PICK(U)                                        \
+  do {                                                      \
+    if (dotPartials) PIPE_LAUNCH(U, true);                  \
+    else PIPE_LAUNCH(U, false);                             \
+  } while (0)
+    if (g_scs_pipe) {
+      switch (g_scs_unroll) {
+      case 2: PIPE_PICK(2); break;
+      case 3: PIPE_PICK(3); break;
+      case 5: PIPE_PICK(5); break;
+      case 7: PIPE_PICK(7); break;
+      case 8: PIPE_PICK(8); break;
+      case 9: PIPE_PICK(9); break;
+      case 14: PIPE_PICK(14); break;
+      default: PIPE_PICK(4); break;
+      }
+    } else
     switch (g_scs_unroll) {
     case 1: SCS_PICK(1); break;
     case 2: SCS_PICK(2); break;
     case 8: SCS_PICK(8); break;
     case 9: SCS_PICK(9); break;
+    case 14: SCS_PICK(14); break;
     default: SCS_PICK(4); break;
     }
+#undef PIPE_PICK
+#undef PIPE_LAUNCH
 #undef SCS_PICK
 #undef SCS_LAUNCH
   } else {
@@ -809,6 +843,8 @@ sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host, con
   s->timing     = false;
   s->evUsed     = 0;
   s->loop_ms    = 0.f;
+  s->spmvTiming = false;
+  s->spmvEvUsed = 0;
   HIP_CHECK(hipEventCreate(&s->evLoop0));
   HIP_CHECK(hipEventCreate(&s->evLoop1));
   for (double& v : s->region_ms) v = 0.0;
@@ -821,6 +857,7 @@ void sb_cg_free(sb_cg* s)
   HIP_CHECK(hipStreamSynchronize(g.stream));
   if (s->iterGraph) HIP_CHECK(hipGraphExecDestroy(s->iterGraph));
   for (hipEvent_t e : s->ev) HIP_CHECK(hipEventDestroy(e));
+  for (hipEvent_t e : s->spmvEv) HIP_CHECK(hipEventDestroy(e));
   HIP_CHECK(hipEventDestroy(s->evLoop0));
   HIP_CHECK(hipEventDestroy(s->evLoop1));
   sb_free(s->r), sb_free(s->Ap), sb_free(s->x), sb_free(s->b), sb_free(s->p), sb_free(s->xexact);
@@ -837,6 +874,35 @@ void sb_cg_set_fused(sb_cg* s, int fused)
   s->fused = fused;
 }
 void sb_cg_set_graph(sb_cg* s, int use_graph) { s->use_graph = use_graph; }
+
+void sb_cg_spmv_timing(sb_cg* s, int on)
+{
+  s->spmvTiming = on != 0;
+  s->spmvEvUsed = 0;
+}
+
+double sb_cg_spmv_ms(sb_cg* s, int* launches)
+{ // sum of the event-bracketed SpMV launches since sb_cg_spmv_timing(s, 1)
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  double total = 0.0;
+  int n        = 0;
+  for (size_t i = 0; i + 1 < s->spmvEvUsed; i += 2) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, s->spmvEv[i], s->spmvEv[i + 1]));
+    total += ms;
+    n++;
+  }
+  if (launches) *launches = n;
+  return total;
+}
+
+void sb_cg_counters(const sb_cg* s, int out[5])
+{ // stop, stop_next, iters, n_rr, n_pAp of the device control block
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  CgScalars h;
+  HIP_CHECK(hipMemcpy(&h, s->S, sizeof h, hipMemcpyDeviceToHost));
+  out[0] = h.stop, out[1] = h.stop_next, out[2] = h.iters, out[3] = h.n_rr, out[4] = h.n_pAp;
+}
 
 static bool can_fuse_dot(const sb_cg* s) { return s->fused && s->A->fmt == 1 && s->A->C == 64; }
 
@@ -859,16 +925,30 @@ template <int MODE> static void scalar_step(sb_cg* s, double eps)
   HIP_CHECK(hipGetLastError());
 }
 
+static void spmv_event(sb_cg* s)
+{
+  if (!s->spmvTiming) return;
+  if (s->spmvEvUsed == s->spmvEv.size()) {
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreate(&e));
+    s->spmvEv.push_back(e);
+  }
+  HIP_CHECK(hipEventRecord(s->spmvEv[s->spmvEvUsed++], g.stream));
+}
+
 static void spmv_and_dot(sb_cg* s, double eps)
 { // COMM: halo ; SPMVM: Ap = A p ; DDOT: p.Ap -> alpha   (src/CGSolver.c:122-126)
   const int* stop = &s->S->stop;
   halo_exchange(s->halo, s->p, stop);
   mark(s, R_COMM);
+  spmv_event(s);
   if (can_fuse_dot(s)) {
     launch_spmv(s->A, s->p, s->Ap, s->partials, stop);
+    spmv_event(s);
     mark(s, R_SPMVM);
   } else {
     launch_spmv(s->A, s->p, s->Ap, nullptr, stop);
+    spmv_event(s);
     mark(s, R_SPMVM);
     launch_dot_partials(s->nr, s->p, s->Ap, s->partials, stop);
   }
@@ -932,7 +1012,7 @@ static void ensure_hist(sb_cg* s, int cap)
 
 static void run_body_maybe_graph(sb_cg* s, double eps)
 { // k >= 2 bodies are iteration-invariant (k lives in the device control block)
-  if (!s->use_graph || g.comm || s->timing) {
+  if (!s->use_graph || g.comm || s->timing || s->spmvTiming) {
     loop_body(s, 2, eps);
     return;
   }
@@ -1052,6 +1132,30 @@ double sb_cg_check_residual(const sb_cg* s)
     sb_d2h(&m, g.scalar, sizeof m);
   }
   return m;
+}
+
+double sb_debug_stream_read_gbs(size_t bytes, int reps)
+{ // raw read ceiling of this device: `reps` passes over a `bytes`-sized buffer
+  need_init();
+  double2* buf = nullptr;
+  HIP_CHECK(hipMalloc(&buf, bytes));
+  HIP_CHECK(hipMemsetAsync(buf, 0, bytes, g.stream));
+  const size_t n2 = bytes / sizeof(double2);
+  dim3 grid((unsigned)g.prop.multiProcessorCount * 8), block(256);
+  hipLaunchKernelGGL(stream_read_k, grid, block, 0, g.stream, buf, n2, g.scalar);
+  hipEvent_t a, b;
+  HIP_CHECK(hipEventCreate(&a));
+  HIP_CHECK(hipEventCreate(&b));
+  HIP_CHECK(hipEventRecord(a, g.stream));
+  for (int r = 0; r < reps; r++) hipLaunchKernelGGL(stream_read_k, grid, block, 0, g.stream, buf, n2, g.scalar);
+  HIP_CHECK(hipEventRecord(b, g.stream));
+  HIP_CHECK(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+  HIP_CHECK(hipEventDestroy(a));
+  HIP_CHECK(hipEventDestroy(b));
+  HIP_CHECK(hipFree(buf));
+  return (double)bytes * reps / (ms * 1e-3) / 1e9;
 }
 
 double sb_cg_loop_ms(const sb_cg* s) { return (double)s->loop_ms; }

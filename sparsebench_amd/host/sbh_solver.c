@@ -183,9 +183,9 @@ void profilerPrint(Comm* c, int iterations)
   if (c->size > 1) printf("Function   Rate(MB/s)  Rate(MFlop/s)  Walltime(s)   [rank 0 of %d]\n", c->size);
   else printf("Function   Rate(MB/s)  Rate(MFlop/s)  Walltime(s)\n");
   for (int j = 0; j < NUMREGIONS - 1; j++) {
-    const double t = _t[j] > 0.0 ? _t[j] : 1e-30;
-    printf("%s%11.2f %11.2f %11.2f\n", kLabel[j], 1.0E-06 * g_words[j] * iterations / t,
-        1.0E-06 * g_flops[j] * iterations / t, _t[j]);
+    const double t = _t[j];
+    printf("%s%11.2f %11.2f %11.2f\n", kLabel[j], t > 0.0 ? 1.0E-06 * g_words[j] * iterations / t : 0.0,
+        t > 0.0 ? 1.0E-06 * g_flops[j] * iterations / t : 0.0, t);
   }
   printf(HLINE);
   if (c->size > 1) {

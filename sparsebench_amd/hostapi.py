@@ -176,6 +176,19 @@ class CG:
     def check_residual(self):
         return self.L.sb_cg_check_residual(self.ptr)
 
+    def counters(self):
+        out = (C.c_int * 5)()
+        self.L.sb_cg_counters(self.ptr, out)
+        return dict(zip(["stop", "stop_next", "iters", "n_rr", "n_pAp"], list(out)))
+
+    def spmv_timing(self, on):
+        self.L.sb_cg_spmv_timing(self.ptr, int(on))
+
+    def spmv_ms(self):
+        n = C.c_int(0)
+        ms = self.L.sb_cg_spmv_ms(self.ptr, C.byref(n))
+        return ms, n.value
+
     def loop_ms(self):
         return self.L.sb_cg_loop_ms(self.ptr)
 

@@ -1,0 +1,148 @@
+"""solveCG on the GPU against the oracle and against histories captured from the
+reference.
+
+Parity chain (DESIGN.md "Parity"):
+  1. GPU history == oracle history with the SAME fixed dot order: bit for bit.
+  2. oracle with the reference's sequential dot == reference strict-IEEE build:
+     bit for bit (tests/test_oracle_pinning.py, CPU).
+  3. link 1 vs link 2 differ only by the summation order inside ddot; the
+     deviation is bounded by the sequential sum's own rounding error and is
+     checked here against the tolerance north_star names (1e-12 relative) on every
+     case where that bound allows it.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REFDATA
+from oracle import pyoracle as po
+from sparsebench_amd import hostapi
+
+pytestmark = pytest.mark.gpu
+
+
+def f(a):
+    return np.array([float(v) for v in a])
+
+
+def run_gpu(filename, n, fmt, Cc, sigma, itermax, eps=0.0, fused=True, graph=False):
+    nx, ny, nz = n if isinstance(n, tuple) else (n, n, n)
+    p = hostapi.Problem(filename, nx, ny, nz, fmt=fmt, Cc=Cc, sigma=sigma)
+    cg = hostapi.CG(p, fused=fused, graph=graph)
+    k = cg.solve(itermax, eps)
+    rr, pap = cg.history()
+    out = dict(k=k, rr=rr, pAp=pap, x=cg.solution(), err=cg.check_residual())
+    cg.free(), p.free()
+    return out
+
+
+CONFIGS = [("crs", 64, 1), ("scs", 64, 1), ("scs", 64, 256), ("scs", 4, 1), ("scs", 128, 512)]
+
+
+@pytest.mark.parametrize("fmt,Cc,sigma", CONFIGS)
+@pytest.mark.parametrize("n", [8, (16, 12, 10), 32])
+def test_history_bit_identical_to_oracle_same_dot_order(gpu, fmt, Cc, sigma, n):
+    dims = n if isinstance(n, tuple) else (n, n, n)
+    g = po.GMatrix.generate(*dims)
+    o = po.cg(g, itermax=60, fmt=fmt, Cc=Cc, sigma=sigma, dot="tree", want_x=True)
+    for fused in (True, False):
+        r = run_gpu("generate", n, fmt, Cc, sigma, 60, fused=fused)
+        assert r["k"] == o["k"]
+        assert np.array_equal(r["rr"], o["rr"]), (fused, "rr")
+        assert np.array_equal(r["pAp"], o["pAp"]), (fused, "pAp")
+        assert np.array_equal(r["x"], o["x"][0]), (fused, "x")
+        assert r["err"] == o["max_err"]
+
+
+def test_graph_replay_gives_the_same_bits(gpu):
+    a = run_gpu("generate", 16, "scs", 64, 1, 50, graph=False)
+    b = run_gpu("generate", 16, "scs", 64, 1, 50, graph=True)
+    assert np.array_equal(a["rr"], b["rr"]) and np.array_equal(a["pAp"], b["pAp"])
+    assert np.array_equal(a["x"], b["x"])
+
+
+def test_band_klein_plumbing_case(gpu, golden_1rank):
+    """configs[0]: exact solve after one step, r.r = [100, 0], NaN alpha, k = 3
+     -- the reference's loop-exit semantics on the device"""
+    gd = golden_1rank["band_klein"]
+    path = os.path.join(REFDATA, "matrix_band_klein.mtx")
+    for fmt, Cc, sg in CONFIGS:
+        r = run_gpu(path, 1, fmt, Cc, sg, 150)
+        assert r["k"] == gd["k"] == 3
+        assert np.array_equal(r["rr"], f(gd["rr"])) and np.array_equal(r["pAp"], f(gd["pAp"]))
+        assert np.all(np.isnan(r["x"]))  # alpha = 0/0 poisons x, as in the reference
+
+
+def test_eps_stops_the_loop_like_the_reference(gpu):
+    g = po.GMatrix.generate(12, 12, 12)
+    for eps in (1e-3, 1e-9, 1e3, 1e9):
+        o = po.cg(g, itermax=80, dot="tree", eps=eps)
+        r = run_gpu("generate", 12, "scs", 64, 1, 80, eps=eps)
+        assert r["k"] == o["k"], eps
+        assert np.array_equal(r["rr"], o["rr"]) and np.array_equal(r["pAp"], o["pAp"]), eps
+    for itermax in (0, 1, 2, 3):
+        o = po.cg(g, itermax=itermax, dot="tree")
+        r = run_gpu("generate", 12, "crs", 64, 1, itermax)
+        assert r["k"] == o["k"] and np.array_equal(r["rr"], o["rr"]), itermax
+
+
+def _rel(a, b):
+    return np.abs(a - b) / np.abs(b)
+
+
+@pytest.mark.parametrize("name,n,fmt,Cc,sigma", [
+    ("hpcg8", 8, "crs", 64, 1), ("hpcg8", 8, "scs", 64, 1), ("hpcg16", 16, "scs", 64, 1),
+    ("hpcg16", 16, "scs", 64, 256), ("hpcg32", 32, "scs", 64, 1), ("hpcg32", 32, "crs", 64, 1)])
+def test_history_vs_reference_1e12(gpu, golden_1rank, name, n, fmt, Cc, sigma):
+    """north_star: residual history within 1e-12 relative of the reference CPU CG.
+    Holds on these sizes while the recurrence is above its own noise floor
+    (r.r/r.r0 >= 1e-20, i.e. ten orders of residual reduction)."""
+    gd = golden_1rank[name]
+    ref_rr, ref_pap = f(gd["rr"]), f(gd["pAp"])
+    r = run_gpu("generate", n, fmt, Cc, sigma, gd["itermax"])
+    assert r["k"] == gd["k"] and len(r["rr"]) == len(ref_rr)
+    live = ref_rr / ref_rr[0] >= 1e-20
+    assert live.sum() >= 10
+    TOL = 1e-12
+    assert _rel(r["rr"], ref_rr)[live].max() <= TOL
+    assert _rel(r["pAp"], ref_pap)[live[:len(ref_pap)]].max() <= TOL
+    # and at every iteration the residual norm agrees to 1e-12 of the initial one
+    assert (np.abs(np.sqrt(r["rr"]) - np.sqrt(ref_rr)) / np.sqrt(ref_rr[0])).max() <= TOL
+
+
+def test_history_vs_reference_64_documented_bound(gpu, golden_1rank):
+    """At 64^3 the reference's OWN sequential ddot carries a rounding error of up to
+    (n-1)*2^-53 = 2.9e-11 relative, so no parallel reduction can track it to 1e-12
+    per iteration; the deviation must stay inside that bound (x4 for the two dots and
+    their propagation), and inside 1e-12 relative to the initial residual norm x4."""
+    gd = golden_1rank["hpcg64"]
+    ref_rr = f(gd["rr"])
+    r = run_gpu("generate", 64, "scs", 64, 1, gd["itermax"])
+    live = ref_rr / ref_rr[0] >= 1e-20
+    n = 64 ** 3
+    assert _rel(r["rr"], ref_rr)[live].max() <= 4 * (n - 1) * 2.0 ** -53
+    assert (np.abs(np.sqrt(r["rr"]) - np.sqrt(ref_rr)) / np.sqrt(ref_rr[0])).max() <= 4e-12
+
+
+def test_full_size_properties_128(gpu, golden_1rank):
+    """BASELINE configs[2] size (128^3, SCS C=64 sigma=256): size-independent checks.
+    r.r0 closed form (exact in fp64), b = A*1 so CG converges to x = 1, SCS == CRS
+    histories bit for bit under the same dot order, fused == unfused."""
+    n = 128
+    a = run_gpu("generate", n, "scs", 64, 1, 60)
+    m = n - 2
+    assert a["rr"][0] == m ** 3 + 600 * m ** 2 + 3072 * m + 3200
+    c = run_gpu("generate", n, "crs", 64, 1, 60)
+    assert np.array_equal(a["rr"], c["rr"]) and np.array_equal(a["pAp"], c["pAp"])
+    u = run_gpu("generate", n, "scs", 64, 1, 60, fused=False)
+    assert np.array_equal(a["rr"], u["rr"]) and np.array_equal(a["x"], u["x"])
+    s = run_gpu("generate", n, "scs", 64, 256, 60)
+    ref_rr = f(golden_1rank["hpcg128"]["rr"])
+    nn = n ** 3
+    for r in (a, s):
+        assert _rel(r["rr"][:len(ref_rr)], ref_rr).max() <= 4 * (nn - 1) * 2.0 ** -53
+        assert (np.abs(np.sqrt(r["rr"][:len(ref_rr)]) - np.sqrt(ref_rr)) / np.sqrt(ref_rr[0])).max() <= (nn - 1) * 2.0 ** -53
+        assert np.all(np.diff(r["rr"][5:]) < 0)  # monotone once past the first steps
+    long = run_gpu("generate", n, "scs", 64, 256, 150)
+    assert long["err"] < 1e-6 and abs(long["x"] - 1.0).max() == long["err"]

@@ -1,0 +1,182 @@
+"""Parity of the HIP kernels against the oracle, through the C-ABI (ctypes), on the
+same inputs.  Bar: BIT-EXACT for SpMV (per-row order kept), waxpby (elementwise) and
+both stages of the fixed-order dot."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REFDATA, load_json
+from oracle import pyoracle as po
+from sparsebench_amd import capi
+from sparsebench_amd.capi import DeviceVector
+
+pytestmark = pytest.mark.gpu
+vp = C.c_void_p
+
+
+def _p(a):
+    return a.ctypes.data_as(vp)
+
+
+def upload_crs(L, g):
+    rp, col, val = (np.ascontiguousarray(a) for a in (g.rowPtr, g.col, g.val))
+    return L.sb_crs_upload(g.nr, g.nc, _p(rp), _p(col), _p(val))
+
+
+def upload_scs(L, s):
+    arrs = [np.ascontiguousarray(a) for a in (s.chunkPtr, s.chunkLens, s.colInd, s.val,
+                                              s.oldToNewPerm, s.newToOldPerm)]
+    return L.sb_scs_upload(s.nr, s.nc, s.C, s.sigma, s.nChunks, s.nElems, *[_p(a) for a in arrs])
+
+
+def gpu_spmv(L, m, x, nr):
+    dx, dy = DeviceVector.from_host(x), DeviceVector(nr)
+    L.sb_spmv(m, dx.ptr, dy.ptr)
+    y = dy.get()
+    dx.free(), dy.free()
+    return y
+
+
+def random_csr(rng, nr, nc, maxlen, empty_rows=True, long_row=None):
+    lens = rng.integers(0 if empty_rows else 1, maxlen + 1, size=nr)
+    if long_row is not None:
+        lens[rng.integers(0, nr)] = long_row
+    rp = np.zeros(nr + 1, dtype=np.uint32)
+    rp[1:] = np.cumsum(lens)
+    col = rng.integers(0, nc, size=int(rp[-1])).astype(np.uint32)
+    val = rng.standard_normal(int(rp[-1]))
+    return po.GMatrix.from_csr(rp, col, val, nc=nc)
+
+
+MATS = ["test%d" % i for i in range(11)] + ["matrix_band_klein"]
+
+
+@pytest.mark.parametrize("name", MATS)
+def test_spmv_reference_matrices_all_formats(gpu, name):
+    L = gpu
+    g = po.GMatrix.from_mtx(os.path.join(REFDATA, name + ".mtx"))
+    ref = np.array([float(v) for v in load_json("spmv_ref.json")[name]])
+    x = np.ones(g.nc)
+    m = upload_crs(L, g)
+    assert np.array_equal(gpu_spmv(L, m, x, g.nr), ref)
+    L.sb_matrix_free(m)
+    rng = np.random.default_rng(1)
+    xr = rng.standard_normal(g.nc)
+    for Cc, sg in ((1, 1), (2, 1), (4, 1), (4, 8), (64, 1), (64, 16), (128, 4), (3, 5)):
+        s = g.to_scs(Cc, sg)
+        m = upload_scs(L, s)
+        assert np.array_equal(gpu_spmv(L, m, x, g.nr), ref), (Cc, sg)
+        assert np.array_equal(gpu_spmv(L, m, xr, g.nr), g.spmv(xr)), (Cc, sg)
+        L.sb_matrix_free(m)
+
+
+@pytest.mark.parametrize("n", [4, 8, 17, 32])
+def test_spmv_hpcg_bit_exact(gpu, n):
+    L = gpu
+    g = po.GMatrix.generate(n, n + 1, n + 2)
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(g.nc)
+    y = g.spmv(x)
+    m = upload_crs(L, g)
+    assert np.array_equal(gpu_spmv(L, m, x, g.nr), y)
+    L.sb_matrix_free(m)
+    for Cc, sg in ((64, 1), (64, 256), (64, 1000000), (32, 64), (256, 512)):
+        s = g.to_scs(Cc, sg)
+        m = upload_scs(L, s)
+        assert L.sb_matrix_is_permuted(m) == int(not np.array_equal(s.oldToNewPerm, np.arange(s.nr)))
+        assert np.array_equal(gpu_spmv(L, m, x, g.nr), y), (Cc, sg)
+        # native (permuted-space) call agrees with the oracle's literal chunk order
+        xp = x[np.asarray(s.newToOldPerm)] if L.sb_matrix_is_permuted(m) else x
+        dx, dy = DeviceVector.from_host(xp), DeviceVector(g.nr)
+        L.sb_spmv_native(m, dx.ptr, dy.ptr)
+        assert np.array_equal(dy.get(), s.spmv_literal(x)[:g.nr]), (Cc, sg)
+        dx.free(), dy.free()
+        L.sb_matrix_free(m)
+
+
+def test_spmv_ragged_random_and_long_rows(gpu):
+    """empty rows, rows longer than one LDS tile (CRS), ragged chunks, nc > nr"""
+    L = gpu
+    rng = np.random.default_rng(11)
+    for nr, nc, maxlen, long_row in ((1, 1, 1, None), (65, 90, 7, None), (1000, 1300, 40, None),
+                                     (300, 300, 9, 9000), (5000, 5000, 3, 4097), (257, 64, 64, None)):
+        g = random_csr(rng, nr, nc, maxlen, long_row=long_row)
+        x = rng.standard_normal(nc)
+        y = g.spmv(x)
+        m = upload_crs(L, g)
+        assert np.array_equal(gpu_spmv(L, m, x, nr), y), ("crs", nr, long_row)
+        L.sb_matrix_free(m)
+        for Cc, sg in ((64, 1), (64, 128), (16, 32)):
+            s = g.to_scs(Cc, sg)
+            m = upload_scs(L, s)
+            assert np.array_equal(gpu_spmv(L, m, x, nr), y), ("scs", nr, Cc, sg)
+            L.sb_matrix_free(m)
+
+
+def test_spmv_empty_matrix(gpu):
+    L = gpu
+    g = po.GMatrix.from_csr(np.zeros(4, dtype=np.uint32), np.zeros(0, dtype=np.uint32), np.zeros(0), nc=3)
+    m = upload_crs(L, g)
+    assert np.array_equal(gpu_spmv(L, m, np.ones(3), 3), np.zeros(3))
+    L.sb_matrix_free(m)
+    s = g.to_scs(64, 1)
+    m = upload_scs(L, s)
+    assert np.array_equal(gpu_spmv(L, m, np.ones(3), 3), np.zeros(3))
+    L.sb_matrix_free(m)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 127, 128, 129, 1000, 4097, 100003, 1 << 20])
+def test_waxpby_and_ddot_bit_exact(gpu, n):
+    L = gpu
+    rng = np.random.default_rng(n + 5)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    dx, dy, dw = DeviceVector.from_host(x), DeviceVector.from_host(y), DeviceVector(n)
+    for a, b in ((1.0, -0.37), (2.5, 1.0), (2.5, -3.0), (1.0, 0.0), (0.0, 0.0)):
+        L.sb_waxpby(n, a, dx.ptr, b, dy.ptr, dw.ptr)
+        assert np.array_equal(dw.get(), po.waxpby(a, x, b, y)), (a, b)
+    # aliasing as solveCG uses it: w == y (src/CGSolver.c:114) and w == x (:127)
+    L.sb_waxpby(n, 1.0, dx.ptr, 0.5, dy.ptr, dy.ptr)
+    y2 = po.waxpby(1.0, x, 0.5, y)
+    assert np.array_equal(dy.get(), y2)
+    L.sb_waxpby(n, 1.0, dx.ptr, -2.0, dy.ptr, dx.ptr)
+    x2 = po.waxpby(1.0, x, -2.0, y2)
+    assert np.array_equal(dx.get(), x2)
+    # fixed-order dot, both stages
+    m = (n + 63) // 64
+    dq = DeviceVector(max(m, 1))
+    L.sb_ddot_partials(n, dx.ptr, dy.ptr, dq.ptr)
+    if m:
+        assert np.array_equal(dq.get()[:m], po.ddot_partials(x2, y2))
+    assert L.sb_ddot(n, dx.ptr, dy.ptr) == po.ddot_tree(x2, y2)
+    assert L.sb_ddot(n, dx.ptr, dx.ptr) == po.ddot_tree(x2, x2)
+    if n:
+        seq = po.ddot_seq(x2, y2)
+        bound = (n - 1) * 2.0 ** -53 * float(np.sum(np.abs(x2 * y2))) + 1e-300
+        assert abs(L.sb_ddot(n, dx.ptr, dy.ptr) - seq) <= bound
+    for v in (dx, dy, dw, dq):
+        v.free()
+
+
+def test_ddot_run_to_run_reproducible(gpu):
+    L = gpu
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(3_000_017)
+    dx = DeviceVector.from_host(x)
+    vals = {L.sb_ddot(len(x), dx.ptr, dx.ptr) for _ in range(5)}
+    assert len(vals) == 1 and vals.pop() == po.ddot_tree(x, x)
+    dx.free()
+
+
+def test_special_values_propagate_like_the_cpu(gpu):
+    """-0.0, inf and NaN take the same path through mul/add as on the CPU"""
+    L = gpu
+    x = np.array([-0.0, 0.0, np.inf, -np.inf, np.nan, 1e308, -1e308, 5e-324] * 9)
+    y = np.array([1.0, -0.0, 0.0, 2.0, 1.0, 10.0, 10.0, 0.5] * 9)
+    dx, dy, dw = DeviceVector.from_host(x), DeviceVector.from_host(y), DeviceVector(len(x))
+    L.sb_waxpby(len(x), 1.0, dx.ptr, 0.0, dy.ptr, dw.ptr)
+    got, exp = dw.get(), po.waxpby(1.0, x, 0.0, y)
+    assert np.array_equal(got.view(np.uint64), exp.view(np.uint64))
+    for v in (dx, dy, dw):
+        v.free()
