@@ -39,22 +39,22 @@ STRICT="-O2 -fno-fast-math -ffp-contract=off -std=c23 -w -fPIC"
 COMMON="$S/CGSolver.c $S/solver.c $S/matrix.c $S/mmio.c $S/allocate.c $S/comm.c $S/bstree.c $S/timing.c $S/profiler.c $S/util.c"
 
 $CLANG -DCRS $DEFS $STRICT -I"$S" -shared -o "$OUT/libsbref_crs.so" \
-  "$HERE/ref_shim.c" $COMMON "$S/matrix-CRS.c" -Wl,--wrap=ddot -lm
+  "$HERE/ref_shim.c" $COMMON "$S/matrix-CRS.c" -Wl,--wrap=ddot -Wl,-Bsymbolic -lm
 
 $CLANG -DSCS $DEFS $STRICT -I"$S" -shared -o "$OUT/libsbref_scs.so" \
-  "$HERE/ref_shim.c" $COMMON "$S/matrix-SCS.c" -Wl,--wrap=ddot -lm
+  "$HERE/ref_shim.c" $COMMON "$S/matrix-SCS.c" -Wl,--wrap=ddot -Wl,-Bsymbolic -lm
 
 TMP=$(mktemp -d)
 trap 'rm -rf "$TMP"' EXIT
 sed -e '/m->C        = (CG_UINT)1;/d' -e '/m->sigma    = (CG_UINT)1;/d' "$S/matrix-SCS.c" > "$TMP/matrix-SCS-fix.c"
 $CLANG -DSCS $DEFS $STRICT -I"$S" -shared -o "$OUT/libsbref_scs_fix.so" \
-  "$HERE/ref_shim.c" $COMMON "$TMP/matrix-SCS-fix.c" -Wl,--wrap=ddot -lm
+  "$HERE/ref_shim.c" $COMMON "$TMP/matrix-SCS-fix.c" -Wl,--wrap=ddot -Wl,-Bsymbolic -lm
 
 # upstream optimisation flags (mk/include_CLANG.mk:15) + OpenMP, timing only
 if $CLANG -fopenmp -x c -o /dev/null -c - <<<'int main(void){return 0;}' 2>/dev/null; then
   $CLANG -DCRS $DEFS -O3 -ffast-math -std=c23 -w -fPIC -fopenmp -I"$S" -shared \
     -o "$OUT/libsbref_crs_omp.so" "$HERE/ref_shim.c" $COMMON "$S/matrix-CRS.c" \
-    -Wl,--wrap=ddot -lm -Wl,-rpath,/opt/rocm/lib/llvm/lib || echo "build_ref: OpenMP variant failed (non-fatal)" >&2
+    -Wl,--wrap=ddot -Wl,-Bsymbolic -lm -Wl,-rpath,/opt/rocm/lib/llvm/lib || echo "build_ref: OpenMP variant failed (non-fatal)" >&2
 fi
 
 # full MPI reference, strict, with the ddot log -> multi-rank golden histories
@@ -62,7 +62,7 @@ MPICC=${MPICC:-/opt/conda/bin/mpicc}
 if [ -x "$MPICC" ]; then
   MPICH_CC=$CLANG "$MPICC" -DCRS -D_MPI $DEFS -O2 -fno-fast-math -ffp-contract=off -std=c23 -w \
     -I"$S" -o "$OUT/sb_ref_mpi" "$HERE/ref_mpi_log.c" $S/main.c $COMMON "$S/matrix-CRS.c" \
-    "$S/matrixBinfile.c" "$S/parameter.c" "$S/affinity.c" -Wl,--wrap=ddot -lm \
+    "$S/matrixBinfile.c" "$S/parameter.c" "$S/affinity.c" -Wl,--wrap=ddot -Wl,-Bsymbolic -lm \
     || echo "build_ref: MPI variant failed (non-fatal)" >&2
 fi
 ls -la "$OUT"

@@ -303,7 +303,9 @@ class Ref:
     def __init__(self, kind="crs"):
         path = os.path.join(HERE, "_ref", "libsbref_%s.so" % kind)
         self.kind = kind
-        L = C.CDLL(path)
+        # the reference exports the same names as the product's drop-in libraries
+        # (matrixGenerate, convertMatrix, ...): bind its calls to its own definitions
+        L = C.CDLL(path, mode=os.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0))
         L.sbref_setup.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.sbref_hist_val.restype = C.c_double
         L.sbref_rowptr.restype = _u32p

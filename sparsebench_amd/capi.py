@@ -43,7 +43,7 @@ def load():
         raise RuntimeError(
             "sparsebench_amd: %s is missing -- build it with `make hip` (hipcc, gfx950). "
             "There is no CPU fallback for the hot path." % LIB_PATH)
-    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(LIB_PATH)
     sig = {
         "sb_init": (None, [C.c_int]),
         "sb_finalize": (None, []),

@@ -623,7 +623,10 @@ void sb_comm_init(int rank, int size, const void* idbytes)
   if (g.comm) SB_FATAL("communicator already initialised");
   if (size < 1 || rank < 0 || rank >= size) SB_FATAL("bad rank %d / size %d", rank, size);
   g.rank = rank, g.size = size;
-  if (size == 1) return; // serial: every comm call degrades to a no-op (src/comm.c:404-411)
+  // serial: every comm call degrades to a no-op (src/comm.c:404-411).  SB_FORCE_RCCL=1
+  // builds a 1-rank RCCL communicator anyway, so the multi-rank kernel sequence and the
+  // RCCL bindings can be exercised on a single GPU.
+  if (size == 1 && !getenv("SB_FORCE_RCCL")) return;
   rccl_open();
   ncclUniqueId id;
   memcpy(&id, idbytes, SB_UNIQUE_ID_BYTES);

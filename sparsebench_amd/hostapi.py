@@ -31,10 +31,10 @@ def host():
     global _host
     if _host is not None:
         return _host
-    capi.load()  # libsbhip.so first (RTLD_GLOBAL): the host library links against it
+    capi.load()  # same libsbhip.so instance the host library links against
     if not os.path.exists(HOST_LIB):
         raise RuntimeError("sparsebench_amd: %s is missing -- run `make host`" % HOST_LIB)
-    H = C.CDLL(HOST_LIB, mode=C.RTLD_GLOBAL)
+    H = C.CDLL(HOST_LIB)
     H.sbh_problem_create.restype = vp
     H.sbh_problem_create.argtypes = [C.c_char_p] + [C.c_int] * 9
     H.sbh_problem_matrix.restype = vp

@@ -146,3 +146,36 @@ def test_full_size_properties_128(gpu, golden_1rank):
         assert np.all(np.diff(r["rr"][5:]) < 0)  # monotone once past the first steps
     long = run_gpu("generate", n, "scs", 64, 256, 150)
     assert long["err"] < 1e-6 and abs(long["x"] - 1.0).max() == long["err"]
+
+
+def test_multi_rank_kernel_sequence_through_rccl_on_one_gpu(gpu, monkeypatch):
+    """SB_FORCE_RCCL=1 attaches a 1-rank RCCL communicator: the CG then takes the
+    multi-rank path (local reduce -> ncclAllReduce on the stream -> scalar update) and
+    ddot / commReduction go through RCCL.  Same bits as the single-rank path."""
+    import ctypes
+    L = gpu
+    base = run_gpu("generate", 16, "scs", 64, 256, 40)
+    monkeypatch.setenv("SB_FORCE_RCCL", "1")
+    raw = (ctypes.c_ubyte * 128)()
+    L.sb_comm_unique_id(raw)
+    L.sb_comm_init(0, 1, raw)
+    try:
+        assert L.sb_comm_size() == 1 and L.sb_comm_rank() == 0
+        r = run_gpu("generate", 16, "scs", 64, 256, 40)
+        u = run_gpu("generate", 16, "crs", 64, 1, 40, fused=False)
+        from sparsebench_amd.capi import DeviceVector
+        x = np.random.default_rng(0).standard_normal(5000)
+        dx = DeviceVector.from_host(x)
+        assert L.sb_ddot(len(x), dx.ptr, dx.ptr) == po.ddot_tree(x, x)
+        one = DeviceVector.from_host(np.array([3.5]))
+        L.sb_comm_reduction(one.ptr, 0)
+        L.sb_comm_reduction(one.ptr, 1)
+        assert one.get()[0] == 3.5
+        L.sb_comm_barrier()
+        dx.free(), one.free()
+    finally:
+        L.sb_comm_finalize()
+    assert np.array_equal(r["rr"], base["rr"]) and np.array_equal(r["pAp"], base["pAp"])
+    assert np.array_equal(r["x"], base["x"]) and r["k"] == base["k"]
+    o = po.cg(po.GMatrix.generate(16, 16, 16), itermax=40, dot="tree")
+    assert np.array_equal(u["rr"], o["rr"])

@@ -1,0 +1,81 @@
+"""The reference-shaped C API end to end on the GPU: a C program written only against
+include/sparsebench/sparsebench.h (tests/c/dropin_driver.c) linked with the per-format
+drop-in library, driven with HOST vectors as the reference's own callers do, plus the
+benchmark executables with the reference's command line."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REFDATA
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "sparsebench_amd", "lib")
+BIN = os.path.join(ROOT, "sparsebench_amd", "bin")
+
+
+def build_driver(fmt):
+    exe = os.path.join(ROOT, "tests", "c", "dropin_driver_%s" % fmt)
+    cmd = ["gcc", "-std=gnu11", "-O1", "-D" + fmt, "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c", "dropin_driver.c"), "-o", exe, "-L" + LIB,
+           "-lsparsebench_%s" % fmt.lower(), "-lsparsebench_host", "-lsbhip", "-Wl,-rpath," + LIB, "-lm"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+@pytest.mark.parametrize("fmt", ["CRS", "SCS"])
+@pytest.mark.parametrize("inp", ["generate", "matrix_band_klein"])
+def test_reference_shaped_c_caller(gpu, fmt, inp):
+    exe = build_driver(fmt)
+    arg = "generate" if inp == "generate" else os.path.join(REFDATA, inp + ".mtx")
+    out = subprocess.run([exe, arg], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    txt = out.stdout.decode()
+    g = po.GMatrix.generate(12, 12, 12) if inp == "generate" else po.GMatrix.from_mtx(arg)
+    x = 1.0 + 0.001 * (np.arange(g.nc) % 97)
+    y = g.spmv(x)
+    got_y = np.array([float(m.group(1)) for m in re.finditer(r"^y \d+ (\S+)$", txt, re.M)])
+    assert np.array_equal(got_y, y)  # spMVM(Matrix*, host x, host y): original row order, any sigma
+    w = po.waxpby(1.0, y, -0.5, x[:g.nr])
+    v = po.waxpby(2.0, w, 1.0, y)
+    got_w = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"^w (\d+) (\S+)$", txt, re.M)}
+    got_v = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"^v (\d+) (\S+)$", txt, re.M)}
+    assert all(got_w[i] == w[i] for i in got_w) and all(got_v[i] == v[i] for i in got_v) and got_w
+    d1, d2 = (float(t) for t in re.search(r"^dot (\S+) (\S+)$", txt, re.M).groups())
+    assert d1 == po.ddot_tree(v, y) and d2 == po.ddot_tree(y, y)
+    o = po.cg(g, itermax=25, fmt=fmt.lower(), Cc=64, sigma=128, dot="tree")
+    assert int(re.search(r"^k (\d+)$", txt, re.M).group(1)) == o["k"]
+    assert "Initial Residual = %E" % np.sqrt(o["rr"][0]) in txt
+    assert re.search(r"Solution performed %d iterations and took \d+\.\d\ds" % o["k"], txt)
+    if inp == "generate":
+        assert "Difference between computed and exact  = %f" % o["max_err"] in txt
+    assert "Function   Rate(MB/s)  Rate(MFlop/s)  Walltime(s)" in txt
+
+
+def test_benchmark_executable_cli(gpu, golden_1rank):
+    """sparseBench-<FMT>-HIP: the reference's flags and output lines"""
+    for exe, extra in (("sparseBench-CRS-HIP", []), ("sparseBench-SCS-HIP", ["-C", "64", "-s", "256"])):
+        out = subprocess.run([os.path.join(BIN, exe), "-x", "32", "-y", "32", "-z", "32", "-i", "50"] + extra,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        txt = out.stdout.decode()
+        assert "Generate 27pt matrix with 3.28e+04 total rows and 8.85e+05 nonzeros" in txt
+        assert "Test type: CG" in txt and re.search(r"Setup took \d+\.\d\ds", txt)
+        rr = np.array([float(v) for v in golden_1rank["hpcg32"]["rr"]])
+        assert "Initial Residual = %E" % np.sqrt(rr[0]) in txt  # 8.138550E+02
+        # printed at %E the GPU history equals the reference's (7 digits)
+        for k in (5, 10, 15, 20, 25, 30):
+            assert "Iteration = %d Residual = %E" % (k, np.sqrt(rr[k - 1])) in txt, k
+        assert "Solution performed 50 iterations" in txt
+        assert "Difference between computed and exact  = 0.000000" in txt
+    out = subprocess.run([os.path.join(BIN, "sparseBench-SCS-HIP"), "-t", "spmv", "-x", "32", "-y", "32",
+                          "-z", "32", "-i", "20"], stdout=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0 and "Test type: SPMVM" in out.stdout.decode()
+    par = os.path.join(ROOT, "tests", "c", "small.par")
+    open(par, "w").write("filename generate #Space is required after string!\nnx 8\nny 8\nnz 8\nitermax 20\neps 0.0\n")
+    out = subprocess.run([os.path.join(BIN, "sparseBench-CRS-HIP"), "-f", par], stdout=subprocess.PIPE, timeout=300)
+    assert "Initial Residual = 2.084418E+02" in out.stdout.decode()  # BASELINE.md, HPCG 8^3
