@@ -78,6 +78,20 @@ int sb_matrix_is_permuted(const sb_matrix* m); /* 1 for SCS with a non-identity 
 /* algorithmic bytes one SpMV moves:
  *   CRS 12*nnz + 4*(nr+1) + 8*nr + 8*nc ; SCS 12*nElems + 8*nChunks + 8*nrPadded + 8*nc */
 double sb_matrix_spmv_bytes(const sb_matrix* m);
+/* SCS C=64 matrices also get a device-private LOSSLESS compressed mirror at upload
+ * (csrc/pack.hip.h; SB_PACK=0 disables it): level 1 = 16-bit column offsets per chunk,
+ * level 2 = additionally a <=256-entry value dictionary.  Results are bit-identical to
+ * the uncompressed kernel; the host-visible arrays keep the reference layout. */
+int sb_matrix_pack_level(const sb_matrix* m);
+/* select the SpMV kernel at run time: 0 reference-layout stream, 1 packed stream with x
+ * gathered through the cache, 2 packed stream with each workgroup's x window staged in LDS
+ * (built when every tile's window fits; SB_PACK=2 stops at mode 1).  Clamped to what the
+ * matrix has; default = the highest available. */
+void sb_matrix_use_packed(sb_matrix* m, int mode);
+int sb_matrix_packed_mode(const sb_matrix* m);
+uint32_t sb_matrix_lds_window(const sb_matrix* m); /* doubles per workgroup, 0 if not built */
+/* bytes the selected SpMV kernel really moves per launch (stream + x + y) */
+double sb_matrix_stream_bytes(const sb_matrix* m);
 
 /* ---- kernels ---------------------------------------------------------------- */
 /* spMVM, src/solver.h:13: y = A x, x has nc entries, y has nr entries, both in

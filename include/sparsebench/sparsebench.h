@@ -200,7 +200,9 @@ int solveCG(Comm* comm, Parameter* param, Matrix* m);
 void spMVM(Matrix* m, const CG_FLOAT* restrict x, CG_FLOAT* restrict y);
 #endif
 void waxpby(const CG_UINT n, const CG_FLOAT alpha, const CG_FLOAT* restrict x,
-            const CG_FLOAT beta, const CG_FLOAT* restrict y, CG_FLOAT* restrict w);
+            const CG_FLOAT beta, const CG_FLOAT* restrict y,
+            CG_FLOAT* w /* may alias x or y, as src/CGSolver.c:114,127 do (the reference's
+                           definition drops `restrict` here too, src/solver.c:21) */);
 void ddot(const CG_UINT n, const CG_FLOAT* restrict x, const CG_FLOAT* restrict y,
           CG_FLOAT* restrict result);
 

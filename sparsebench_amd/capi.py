@@ -27,6 +27,8 @@ SYMBOLS = [
     "sb_cg_history", "sb_cg_solution", "sb_cg_check_residual", "sb_cg_region_ms", "sb_version",
     "sb_comm_allgather_bytes", "sb_comm_alltoallv_ints", "sb_comm_barrier", "sb_cg_loop_ms",
     "sb_cg_spmv_timing", "sb_cg_spmv_ms", "sb_cg_counters", "sb_debug_stream_read_gbs",
+    "sb_matrix_pack_level", "sb_matrix_use_packed", "sb_matrix_stream_bytes",
+    "sb_matrix_packed_mode", "sb_matrix_lds_window",
 ]
 
 _lib = None
@@ -109,6 +111,11 @@ def load():
         "sb_cg_spmv_ms": (C.c_double, [vp, C.POINTER(C.c_int)]),
         "sb_cg_counters": (None, [vp, vp]),
         "sb_debug_stream_read_gbs": (C.c_double, [C.c_size_t, C.c_int]),
+        "sb_matrix_pack_level": (C.c_int, [vp]),
+        "sb_matrix_use_packed": (None, [vp, C.c_int]),
+        "sb_matrix_stream_bytes": (C.c_double, [vp]),
+        "sb_matrix_packed_mode": (C.c_int, [vp]),
+        "sb_matrix_lds_window": (C.c_uint32, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

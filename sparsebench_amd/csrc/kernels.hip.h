@@ -434,8 +434,16 @@ __device__ __forceinline__ double reduce_final_block(uint32_t m, const double* _
 {
   double s   = 0.0;
   uint32_t i = threadIdx.x;
-  // same order as the plain loop, but 8 independent loads are in flight at a time
-  // (the partials were written by other CUs: every load is an L2/fabric round trip)
+  // same order as the plain loop, but 32 / 8 independent loads are in flight at a time
+  // (the partials were written by other CUs: every load is an L2/fabric round trip,
+  // and this single workgroup sits on the critical path of every CG iteration)
+  for (; i + 31u * 1024u < m; i += 32u * 1024u) {
+    double a[32];
+#pragma unroll
+    for (int u = 0; u < 32; u++) a[u] = q[i + (uint32_t)u * 1024u];
+#pragma unroll
+    for (int u = 0; u < 32; u++) s = s + a[u];
+  }
   for (; i + 7u * 1024u < m; i += 8u * 1024u) {
     double a[8];
 #pragma unroll

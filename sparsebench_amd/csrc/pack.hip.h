@@ -1,0 +1,547 @@
+// pack.hip.h -- device-private, LOSSLESS compression of the Sell-C-sigma (C = 64) stream.
+//
+// The matrix stream is 77 % of the bytes a CG iteration moves, and the kernel is
+// HBM-bound, so bytes are time.  Two general, automatically detected encodings:
+//
+//   values   if the matrix holds <= 256 distinct fp64 bit patterns (stencils, graph
+//            Laplacians, ...): one byte per element indexing a dictionary held in LDS;
+//            otherwise the fp64 values are streamed as before;
+//   columns  per chunk, 16-bit offsets from the chunk's smallest column when the chunk's
+//            columns span < 65535 (banded / stencil / well-ordered matrices); chunks that
+//            do not qualify (e.g. rows touching halo columns) keep 32-bit indices.
+//
+// Elements are regrouped so that a lane fetches four consecutive columns of its row
+// with one load: 8 B (or 16 B wide) of indices + 4 B of codes per lane per group,
+// i.e. 512 B / 1 KiB / 256 B per wave-instruction.  The host-visible arrays keep the
+// reference layout (src/SCSMatrix.h); this is a private mirror built once at upload.
+// Decoded (column, value) pairs are bit-identical to the originals and are consumed
+// in the same left-to-right order, so results do not change by a single bit.
+//
+// Reference semantics of padding (column 0, value 0.0, src/matrix-SCS.c:146-155) are
+// kept: a padded element is encoded as the marker 0xFFFF and decodes to `padCol`
+// (column 0, renumbered like any other column when sigma > 1).
+#pragma once
+#include "kernels.hip.h"
+
+namespace sbk {
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct PackMeta {
+  uint32_t grp;    // groups of 4 columns before this chunk (code stream position)
+  uint32_t idxOff; // index stream position in 512-B units (a wide group takes two)
+  uint32_t base;   // smallest column of the chunk (narrow chunks)
+  uint32_t info;   // bit 31: wide (32-bit indices); bits 0..30: chunk width (columns)
+};
+
+constexpr uint32_t PACK_PAD = 0xFFFFu;
+
+// ---- analysis / packing (run once at upload) --------------------------------------
+__global__ __launch_bounds__(256) void pack_minmax_k(const uint32_t* __restrict__ chunkPtr,
+    const uint32_t* __restrict__ chunkLens, const uint32_t* __restrict__ colInd,
+    const double* __restrict__ val, uint32_t nChunks, uint32_t padCol, uint32_t* __restrict__ cmin,
+    uint32_t* __restrict__ cmax)
+{
+  const uint32_t chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t lane  = threadIdx.x & 63u;
+  if (chunk >= nChunks) return;
+  const uint32_t cp = chunkPtr[chunk], len = chunkLens[chunk];
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+  for (uint32_t j = 0; j < len; j++) {
+    const uint32_t c = colInd[(size_t)cp + (size_t)j * 64 + lane];
+    const double v   = val[(size_t)cp + (size_t)j * 64 + lane];
+    const bool pad   = c == padCol && __double_as_longlong(v) == 0;
+    if (!pad) {
+      lo = min(lo, c);
+      hi = max(hi, c);
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+    hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+  }
+  if (lane == 0) cmin[chunk] = lo, cmax[chunk] = hi;
+}
+
+__device__ __forceinline__ uint32_t dict_code(const unsigned long long* __restrict__ dict, int n,
+    unsigned long long bits)
+{ // dict is sorted by bit pattern; the value is known to be present
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (dict[mid] < bits) lo = mid + 1;
+    else hi = mid;
+  }
+  return (uint32_t)lo;
+}
+
+__global__ __launch_bounds__(256) void pack_write_k(const uint32_t* __restrict__ chunkPtr,
+    const uint32_t* __restrict__ chunkLens, const uint32_t* __restrict__ colInd,
+    const double* __restrict__ val, const PackMeta* __restrict__ meta,
+    const unsigned long long* __restrict__ dictBits, int nDict, uint32_t nChunks, uint32_t padCol,
+    uint32_t* __restrict__ idxOut, uint32_t* __restrict__ codesOut)
+{
+  const uint32_t chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t lane  = threadIdx.x & 63u;
+  if (chunk >= nChunks) return;
+  const uint32_t cp = chunkPtr[chunk], len = chunkLens[chunk];
+  const PackMeta m  = meta[chunk];
+  const bool wide   = m.info >> 31;
+  const uint32_t ng = (len + 3u) >> 2;
+  for (uint32_t g = 0; g < ng; g++) {
+    uint32_t c[4], code = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t j = g * 4u + k;
+      uint32_t col     = padCol;
+      double v         = 0.0;
+      if (j < len) {
+        col = colInd[(size_t)cp + (size_t)j * 64 + lane];
+        v   = val[(size_t)cp + (size_t)j * 64 + lane];
+      }
+      const bool pad = col == padCol && __double_as_longlong(v) == 0;
+      c[k]           = wide ? col : (pad ? PACK_PAD : col - m.base);
+      if (nDict > 0) code |= dict_code(dictBits, nDict, (unsigned long long)__double_as_longlong(v)) << (8u * k);
+    }
+    if (wide) {
+      uint32_t* o = idxOut + (size_t)m.idxOff * 128 + (size_t)g * 256 + lane * 4; // 16 B per lane
+      o[0] = c[0], o[1] = c[1], o[2] = c[2], o[3] = c[3];
+    } else {
+      uint32_t* o = idxOut + ((size_t)(m.idxOff + g) * 64 + lane) * 2; // 8 B per lane
+      o[0] = c[0] | (c[1] << 16), o[1] = c[2] | (c[3] << 16);
+    }
+    if (nDict > 0) codesOut[(size_t)(m.grp + g) * 64 + lane] = code;
+  }
+}
+
+// ---- SpMV on the packed stream --------------------------------------------------------
+// One wavefront per chunk, lane = row, exactly as spmv_scs64; per group of four columns
+// a lane issues one index load, one code load (DICT) and four x gathers.
+template <bool DICT, bool DOT>
+__global__ __launch_bounds__(256) void spmv_scs64_packed(const PackMeta* __restrict__ meta,
+    const uint32_t* __restrict__ idx, const uint32_t* __restrict__ codes,
+    const double* __restrict__ dict, const uint32_t* __restrict__ chunkPtr,
+    const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y, uint32_t nr,
+    uint32_t nChunks, uint32_t blocksPerXcd, uint32_t padCol, double* __restrict__ dotPartials,
+    const int* __restrict__ stop)
+{
+  __shared__ double sdict[256];
+  if (DICT) {
+    sdict[threadIdx.x] = dict[threadIdx.x];
+    __syncthreads();
+  }
+  const int stopped    = stop ? *stop : 0;
+  const uint32_t lb    = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
+  const uint32_t chunk = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
+  const uint32_t lane  = threadIdx.x & 63u;
+  if (chunk >= nChunks) return;
+  const PackMeta m   = meta[chunk];
+  const uint32_t cpv = DICT ? 0u : chunkPtr[chunk];
+  if (stopped) return;
+  const uint32_t len = m.info & 0x7FFFFFFFu;
+  const bool wide    = m.info >> 31;
+  const uint32_t nFull = len >> 2, rem = len & 3u;
+  const uint32_t* cstream = codes + (size_t)m.grp * 64 + lane;
+  const double* vraw      = val + cpv + lane;
+  double acc              = 0.0;
+
+#define SB_ACCUM(G, K, COL)                                                              \
+  do {                                                                                   \
+    const double xv_ = x[COL];                                                           \
+    const double vv_ = DICT ? sdict[(cw >> (8u * (K))) & 255u]                           \
+                            : stream_load(vraw + (size_t)((G) * 4u + (K)) * 64);         \
+    acc = acc + vv_ * xv_;                                                               \
+  } while (0)
+
+  if (!wide) {
+    const u32x2* istream = reinterpret_cast<const u32x2*>(idx) + (size_t)m.idxOff * 64 + lane;
+    uint32_t g = 0;
+    for (; g + 2 <= nFull; g += 2) { // 8 columns in flight
+      const u32x2 i0 = stream_load(istream + (size_t)g * 64);
+      const u32x2 i1 = stream_load(istream + (size_t)(g + 1) * 64);
+      uint32_t cw0 = 0, cw1 = 0;
+      if (DICT) cw0 = stream_load(cstream + (size_t)g * 64), cw1 = stream_load(cstream + (size_t)(g + 1) * 64);
+      uint32_t d[8] = { i0.x & 0xFFFFu, i0.x >> 16, i0.y & 0xFFFFu, i0.y >> 16,
+                        i1.x & 0xFFFFu, i1.x >> 16, i1.y & 0xFFFFu, i1.y >> 16 };
+      double xv[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) xv[k] = x[d[k] == PACK_PAD ? padCol : m.base + d[k]];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t cw = k < 4 ? cw0 : cw1;
+        const double vv   = DICT ? sdict[(cw >> (8u * (k & 3))) & 255u]
+                                 : stream_load(vraw + (size_t)((g + (k >> 2)) * 4u + (k & 3)) * 64);
+        acc = acc + vv * xv[k];
+      }
+    }
+    for (; g < nFull; g++) {
+      const u32x2 i0    = stream_load(istream + (size_t)g * 64);
+      const uint32_t cw = DICT ? stream_load(cstream + (size_t)g * 64) : 0u;
+      const uint32_t d[4] = { i0.x & 0xFFFFu, i0.x >> 16, i0.y & 0xFFFFu, i0.y >> 16 };
+#pragma unroll
+      for (int k = 0; k < 4; k++) SB_ACCUM(g, k, d[k] == PACK_PAD ? padCol : m.base + d[k]);
+    }
+    if (rem) { // last, partial group: columns beyond the chunk's width are not accumulated
+      const u32x2 i0    = stream_load(istream + (size_t)nFull * 64);
+      const uint32_t cw = DICT ? stream_load(cstream + (size_t)nFull * 64) : 0u;
+      const uint32_t d[4] = { i0.x & 0xFFFFu, i0.x >> 16, i0.y & 0xFFFFu, i0.y >> 16 };
+      for (uint32_t k = 0; k < rem; k++) SB_ACCUM(nFull, k, d[k] == PACK_PAD ? padCol : m.base + d[k]);
+    }
+  } else {
+    const u32x4* istream = reinterpret_cast<const u32x4*>(idx + (size_t)m.idxOff * 128) + lane;
+    for (uint32_t g = 0; g < nFull; g++) {
+      const u32x4 i0    = stream_load(istream + (size_t)g * 64);
+      const uint32_t cw = DICT ? stream_load(cstream + (size_t)g * 64) : 0u;
+      const uint32_t d[4] = { i0.x, i0.y, i0.z, i0.w };
+#pragma unroll
+      for (int k = 0; k < 4; k++) SB_ACCUM(g, k, d[k]);
+    }
+    if (rem) {
+      const u32x4 i0    = stream_load(istream + (size_t)nFull * 64);
+      const uint32_t cw = DICT ? stream_load(cstream + (size_t)nFull * 64) : 0u;
+      const uint32_t d[4] = { i0.x, i0.y, i0.z, i0.w };
+      for (uint32_t k = 0; k < rem; k++) SB_ACCUM(nFull, k, d[k]);
+    }
+  }
+#undef SB_ACCUM
+  const uint32_t row = chunk * 64u + lane;
+  if (row < nr) y[row] = acc;
+  if (DOT) {
+    double t = row < nr ? x[row] * acc : 0.0;
+    t        = butterfly64(t);
+    if (lane == 0) dotPartials[chunk] = t;
+  }
+}
+
+// "One HBM round trip per chunk" form.  PMC of the simple loop shows waves waiting 74 %
+// of their cycles: per chunk it chains ~4 x (stream load -> gather -> accumulate).  Here a
+// wave first fetches the indices/codes of up to SG groups (a whole HPCG chunk: 7 groups,
+// 24 VGPRs) in one burst, then gathers and accumulates eight columns at a time, so the
+// chain is one HBM latency plus a few L1/L2 latencies, at full occupancy (<= 64 VGPRs).
+template <bool DICT, bool DOT, int SG>
+__global__ __launch_bounds__(256) void spmv_scs64_packed_c(const PackMeta* __restrict__ meta,
+    const uint32_t* __restrict__ idx, const uint32_t* __restrict__ codes,
+    const double* __restrict__ dict, const uint32_t* __restrict__ chunkPtr,
+    const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y, uint32_t nr,
+    uint32_t nChunks, uint32_t blocksPerXcd, uint32_t padCol, double* __restrict__ dotPartials,
+    const int* __restrict__ stop)
+{
+  __shared__ double sdict[256];
+  if (DICT) {
+    sdict[threadIdx.x] = dict[threadIdx.x];
+    __syncthreads();
+  }
+  const int stopped    = stop ? *stop : 0;
+  const uint32_t lb    = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
+  const uint32_t chunk = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
+  const uint32_t lane  = threadIdx.x & 63u;
+  if (chunk >= nChunks) return;
+  const PackMeta m   = meta[chunk];
+  const uint32_t cpv = DICT ? 0u : chunkPtr[chunk];
+  if (stopped) return;
+  const uint32_t len      = m.info & 0x7FFFFFFFu;
+  const bool wide         = m.info >> 31;
+  const uint32_t ng       = (len + 3u) >> 2;
+  const uint32_t* cstream = codes + (size_t)m.grp * 64 + lane;
+  const double* vraw      = val + cpv + lane;
+  double acc              = 0.0;
+  if (!wide) {
+    const u32x2* istream = reinterpret_cast<const u32x2*>(idx) + (size_t)m.idxOff * 64 + lane;
+    for (uint32_t b0 = 0; b0 < ng; b0 += SG) {
+      u32x2 iv[SG];
+      uint32_t cw[SG];
+#pragma unroll
+      for (int gi = 0; gi < SG; gi++) {
+        iv[gi] = u32x2{ 0u, 0u }, cw[gi] = 0u;
+        if (b0 + gi < ng) {
+          iv[gi] = stream_load(istream + (size_t)(b0 + gi) * 64);
+          if (DICT) cw[gi] = stream_load(cstream + (size_t)(b0 + gi) * 64);
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < SG; s2 += 2) {
+        if (b0 + s2 < ng) {
+          double xv[8];
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const u32x2 w       = iv[s2 + q];
+            const uint32_t d[4] = { w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16 };
+#pragma unroll
+            for (int k = 0; k < 4; k++) xv[q * 4 + k] = x[d[k] == PACK_PAD ? padCol : m.base + d[k]];
+          }
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const uint32_t j = (b0 + s2 + q) * 4u + k;
+              if (j < len) {
+                const double vv = DICT ? sdict[(cw[s2 + q] >> (8u * k)) & 255u] : stream_load(vraw + (size_t)j * 64);
+                acc             = acc + vv * xv[q * 4 + k];
+              }
+            }
+          }
+        }
+      }
+    }
+  } else {
+    const u32x4* istream = reinterpret_cast<const u32x4*>(idx + (size_t)m.idxOff * 128) + lane;
+    for (uint32_t g = 0; g < ng; g++) {
+      const u32x4 i0      = stream_load(istream + (size_t)g * 64);
+      const uint32_t cw0  = DICT ? stream_load(cstream + (size_t)g * 64) : 0u;
+      const uint32_t d[4] = { i0.x, i0.y, i0.z, i0.w };
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t j = g * 4u + k;
+        if (j < len) {
+          const double vv = DICT ? sdict[(cw0 >> (8u * k)) & 255u] : stream_load(vraw + (size_t)j * 64);
+          acc             = acc + vv * x[d[k]];
+        }
+      }
+    }
+  }
+  const uint32_t row = chunk * 64u + lane;
+  if (row < nr) y[row] = acc;
+  if (DOT) {
+    double t = row < nr ? x[row] * acc : 0.0;
+    t        = butterfly64(t);
+    if (lane == 0) dotPartials[chunk] = t;
+  }
+}
+
+// ---- level 3: the x window of a tile staged in LDS -------------------------------------
+// With 3 bytes per element the kernel is no longer HBM-bound; PMC shows the vector
+// memory pipe busy with the gathers (27 per row, ~16 L1 requests per wave-instruction,
+// 90 % L1 hits) and waves waiting on them.  A tile = the 4 chunks (256 rows) of one
+// workgroup.  At pack time the host lists, per tile, the few contiguous column ranges
+// ("segments") its rows touch -- for a 27-point stencil 3 ranges of ~514 entries, for a
+// rank-boundary tile additionally a range of halo columns -- and every element's 16-bit
+// code becomes a SLOT in that window (slot 0 always holds x[padCol], so padding needs no
+// special case).  The workgroup copies the segments of x into LDS with coalesced loads,
+// then every x "gather" is a ds_read_b64 (2 LDS cycles per wave-instruction instead of a
+// trip through the vector cache).  Values still come from the dictionary or the fp64
+// stream; order and bits are unchanged.
+struct TileSeg {
+  uint32_t col; // first column of the segment (device numbering)
+  uint32_t len; // entries
+  uint32_t lds; // first slot in the tile's window
+  uint32_t pad_;
+};
+
+__global__ __launch_bounds__(256) void pack_slots_k(const uint32_t* __restrict__ chunkPtr,
+    const uint32_t* __restrict__ chunkLens, const uint32_t* __restrict__ colInd,
+    const double* __restrict__ val, const PackMeta* __restrict__ meta,
+    const uint32_t* __restrict__ tileSegPtr, const TileSeg* __restrict__ segs, uint32_t nChunks,
+    uint32_t padCol, uint32_t* __restrict__ slotOut)
+{
+  const uint32_t tile  = blockIdx.x;
+  const uint32_t chunk = tile * 4u + (threadIdx.x >> 6);
+  const uint32_t lane  = threadIdx.x & 63u;
+  if (chunk >= nChunks) return;
+  const uint32_t s0 = tileSegPtr[tile], s1 = tileSegPtr[tile + 1];
+  const uint32_t cp = chunkPtr[chunk], len = chunkLens[chunk];
+  const PackMeta m  = meta[chunk];
+  const uint32_t ng = (len + 3u) >> 2;
+  for (uint32_t g = 0; g < ng; g++) {
+    uint32_t sl[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t j = g * 4u + k;
+      uint32_t slot    = 0; // x[padCol]
+      if (j < len) {
+        const uint32_t col = colInd[(size_t)cp + (size_t)j * 64 + lane];
+        const double v     = val[(size_t)cp + (size_t)j * 64 + lane];
+        if (!(col == padCol && __double_as_longlong(v) == 0)) {
+          uint32_t lo = s0, hi = s1 - 1; // last segment whose first column <= col
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (segs[mid].col <= col) lo = mid;
+            else hi = mid - 1;
+          }
+          slot = segs[lo].lds + (col - segs[lo].col);
+        }
+      }
+      sl[k] = slot;
+    }
+    uint32_t* o = slotOut + ((size_t)(m.grp + g) * 64 + lane) * 2;
+    o[0] = sl[0] | (sl[1] << 16), o[1] = sl[2] | (sl[3] << 16);
+  }
+}
+
+template <bool DICT, bool DOT>
+__global__ __launch_bounds__(256) void spmv_scs64_lds(const PackMeta* __restrict__ meta,
+    const uint32_t* __restrict__ slots, const uint32_t* __restrict__ codes,
+    const double* __restrict__ dict, const uint32_t* __restrict__ chunkPtr,
+    const double* __restrict__ val, const uint32_t* __restrict__ tileSegPtr,
+    const TileSeg* __restrict__ segs, const double* __restrict__ x, double* __restrict__ y, uint32_t nr,
+    uint32_t nChunks, uint32_t blocksPerXcd, uint32_t padCol, double* __restrict__ dotPartials,
+    const int* __restrict__ stop)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[]; // [256 dict][window]
+  double* sdict = lds;
+  double* sx    = lds + 256;
+  const int stopped   = stop ? *stop : 0;
+  const uint32_t tile = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
+  const uint32_t nTiles = (nChunks + 3u) >> 2;
+  if (tile >= nTiles || stopped) return; // uniform per workgroup
+  if (DICT) sdict[threadIdx.x] = dict[threadIdx.x];
+  if (threadIdx.x == 0) sx[0] = x[padCol]; // slot 0: what padding multiplies (src/matrix-SCS.c:151-155)
+  const uint32_t s0 = tileSegPtr[tile], s1 = tileSegPtr[tile + 1];
+  for (uint32_t s = s0; s < s1; s++) {
+    const TileSeg sg = segs[s];
+    for (uint32_t i = threadIdx.x; i < sg.len; i += 256u) sx[sg.lds + i] = x[sg.col + i];
+  }
+  __syncthreads();
+  const uint32_t chunk = __builtin_amdgcn_readfirstlane(tile * 4u + (threadIdx.x >> 6));
+  const uint32_t lane  = threadIdx.x & 63u;
+  if (chunk >= nChunks) return;
+  const PackMeta m   = meta[chunk];
+  const uint32_t cpv = DICT ? 0u : chunkPtr[chunk];
+  const uint32_t len = m.info & 0x7FFFFFFFu;
+  const uint32_t nFull = len >> 2, rem = len & 3u;
+  const u32x2* sstream    = reinterpret_cast<const u32x2*>(slots) + (size_t)m.grp * 64 + lane;
+  const uint32_t* cstream = codes + (size_t)m.grp * 64 + lane;
+  const double* vraw      = val + cpv + lane;
+  double acc              = 0.0;
+  uint32_t g              = 0;
+  for (; g + 2 <= nFull; g += 2) {
+    const u32x2 i0 = stream_load(sstream + (size_t)g * 64);
+    const u32x2 i1 = stream_load(sstream + (size_t)(g + 1) * 64);
+    uint32_t cw0 = 0, cw1 = 0;
+    if (DICT) cw0 = stream_load(cstream + (size_t)g * 64), cw1 = stream_load(cstream + (size_t)(g + 1) * 64);
+    const uint32_t d[8] = { i0.x & 0xFFFFu, i0.x >> 16, i0.y & 0xFFFFu, i0.y >> 16,
+                            i1.x & 0xFFFFu, i1.x >> 16, i1.y & 0xFFFFu, i1.y >> 16 };
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t cw = k < 4 ? cw0 : cw1;
+      const double vv   = DICT ? sdict[(cw >> (8u * (k & 3))) & 255u]
+                               : stream_load(vraw + (size_t)((g + (k >> 2)) * 4u + (k & 3)) * 64);
+      acc = acc + vv * sx[d[k]];
+    }
+  }
+  for (; g < nFull + (rem ? 1u : 0u); g++) {
+    const u32x2 i0      = stream_load(sstream + (size_t)g * 64);
+    const uint32_t cw   = DICT ? stream_load(cstream + (size_t)g * 64) : 0u;
+    const uint32_t d[4] = { i0.x & 0xFFFFu, i0.x >> 16, i0.y & 0xFFFFu, i0.y >> 16 };
+    const uint32_t kmax = g < nFull ? 4u : rem;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      if (k < kmax) { // wave-uniform
+        const double vv = DICT ? sdict[(cw >> (8u * k)) & 255u] : stream_load(vraw + (size_t)(g * 4u + k) * 64);
+        acc             = acc + vv * sx[d[k]];
+      }
+    }
+  }
+  const uint32_t row = chunk * 64u + lane;
+  if (row < nr) y[row] = acc;
+  if (DOT) {
+    double t = row < nr ? x[row] * acc : 0.0;
+    t        = butterfly64(t);
+    if (lane == 0) dotPartials[chunk] = t;
+  }
+}
+
+// Batched + prefetching form for narrow chunks.  With 3 bytes per element the kernel is
+// no longer HBM-bound but latency-bound (stream load -> gather -> accumulate per group),
+// so a wave keeps GB groups (4*GB columns) of gathers in flight at once and fetches the
+// next batch's indices/codes while the current gathers are outstanding.  Wide chunks
+// fall back to the simple loop.  Same per-row order and bits.
+template <bool DICT, bool DOT, int GB>
+__global__ __launch_bounds__(256) void spmv_scs64_packed_b(const PackMeta* __restrict__ meta,
+    const uint32_t* __restrict__ idx, const uint32_t* __restrict__ codes,
+    const double* __restrict__ dict, const uint32_t* __restrict__ chunkPtr,
+    const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y, uint32_t nr,
+    uint32_t nChunks, uint32_t blocksPerXcd, uint32_t padCol, double* __restrict__ dotPartials,
+    const int* __restrict__ stop)
+{
+  __shared__ double sdict[256];
+  if (DICT) {
+    sdict[threadIdx.x] = dict[threadIdx.x];
+    __syncthreads();
+  }
+  const int stopped    = stop ? *stop : 0;
+  const uint32_t lb    = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
+  const uint32_t chunk = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
+  const uint32_t lane  = threadIdx.x & 63u;
+  if (chunk >= nChunks) return;
+  const PackMeta m   = meta[chunk];
+  const uint32_t cpv = DICT ? 0u : chunkPtr[chunk];
+  if (stopped) return;
+  const uint32_t len      = m.info & 0x7FFFFFFFu;
+  const bool wide         = m.info >> 31;
+  const uint32_t ng       = (len + 3u) >> 2;
+  const uint32_t* cstream = codes + (size_t)m.grp * 64 + lane;
+  const double* vraw      = val + cpv + lane;
+  double acc              = 0.0;
+  if (!wide) {
+    const u32x2* istream = reinterpret_cast<const u32x2*>(idx) + (size_t)m.idxOff * 64 + lane;
+    u32x2 iv[GB], ivn[GB];
+    uint32_t cw[GB], cwn[GB];
+#pragma unroll
+    for (int gi = 0; gi < GB; gi++) {
+      iv[gi] = u32x2{ 0u, 0u }, cw[gi] = 0u, ivn[gi] = u32x2{ 0u, 0u }, cwn[gi] = 0u;
+      if ((uint32_t)gi < ng) {
+        iv[gi] = stream_load(istream + (size_t)gi * 64);
+        if (DICT) cw[gi] = stream_load(cstream + (size_t)gi * 64);
+      }
+    }
+    for (uint32_t b = 0; b < ng; b += GB) {
+      double xv[GB * 4];
+#pragma unroll
+      for (int gi = 0; gi < GB; gi++) {
+        if (b + gi < ng) {
+          const uint32_t d[4] = { iv[gi].x & 0xFFFFu, iv[gi].x >> 16, iv[gi].y & 0xFFFFu, iv[gi].y >> 16 };
+#pragma unroll
+          for (int k = 0; k < 4; k++) xv[gi * 4 + k] = x[d[k] == PACK_PAD ? padCol : m.base + d[k]];
+        }
+      }
+#pragma unroll
+      for (int gi = 0; gi < GB; gi++) {
+        if (b + GB + gi < ng) {
+          ivn[gi] = stream_load(istream + (size_t)(b + GB + gi) * 64);
+          if (DICT) cwn[gi] = stream_load(cstream + (size_t)(b + GB + gi) * 64);
+        }
+      }
+#pragma unroll
+      for (int gi = 0; gi < GB; gi++) {
+        if (b + gi < ng) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const uint32_t j = (b + gi) * 4u + k;
+            if (j < len) {
+              const double vv = DICT ? sdict[(cw[gi] >> (8u * k)) & 255u] : stream_load(vraw + (size_t)j * 64);
+              acc             = acc + vv * xv[gi * 4 + k];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int gi = 0; gi < GB; gi++) iv[gi] = ivn[gi], cw[gi] = cwn[gi];
+    }
+  } else {
+    const u32x4* istream = reinterpret_cast<const u32x4*>(idx + (size_t)m.idxOff * 128) + lane;
+    for (uint32_t g = 0; g < ng; g++) {
+      const u32x4 i0      = stream_load(istream + (size_t)g * 64);
+      const uint32_t cw0  = DICT ? stream_load(cstream + (size_t)g * 64) : 0u;
+      const uint32_t d[4] = { i0.x, i0.y, i0.z, i0.w };
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t j = g * 4u + k;
+        if (j < len) {
+          const double vv = DICT ? sdict[(cw0 >> (8u * k)) & 255u] : stream_load(vraw + (size_t)j * 64);
+          acc             = acc + vv * x[d[k]];
+        }
+      }
+    }
+  }
+  const uint32_t row = chunk * 64u + lane;
+  if (row < nr) y[row] = acc;
+  if (DOT) {
+    double t = row < nr ? x[row] * acc : 0.0;
+    t        = butterfly64(t);
+    if (lane == 0) dotPartials[chunk] = t;
+  }
+}
+
+} // namespace sbk

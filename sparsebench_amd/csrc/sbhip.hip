@@ -16,6 +16,9 @@
 #include <vector>
 
 #include "kernels.hip.h"
+#include "pack.hip.h"
+
+#include <algorithm>
 
 using namespace sbk;
 
@@ -157,6 +160,22 @@ struct sb_matrix {
   // both
   uint32_t* colInd = nullptr;
   double* val = nullptr;
+  // SCS C=64: device-private compressed mirror (pack.hip.h)
+  PackMeta* pmeta = nullptr;
+  uint32_t *pidx = nullptr, *pcodes = nullptr;
+  double* pdict = nullptr;
+  int packLevel = 0; // 0 none, 1 16-bit columns, 2 + value dictionary
+  int usePacked = 0;
+  uint32_t padCol = 0;
+  double packedBytes = 0.0; // matrix-stream bytes of the packed form
+  uint32_t nWideChunks = 0;
+  int nDict = 0;
+  // level 3: per-tile x windows staged in LDS
+  uint32_t* tileSegPtr = nullptr;
+  TileSeg* tileSegs    = nullptr;
+  uint32_t* pslots     = nullptr;
+  uint32_t ldsWindow   = 0; // doubles, incl. slot 0
+  double slotBytes     = 0.0;
 };
 
 struct sb_halo {
@@ -357,6 +376,180 @@ __global__ void remap_cols_k(uint32_t n, uint32_t nr, const uint32_t* __restrict
   }
 }
 
+// Build the compressed mirror of an uploaded SCS C=64 matrix (pack.hip.h).  hostVal is
+// the host copy of val (dictionary detection happens on the host, with early exit).
+static void build_packed(sb_matrix* m, const double* hostVal, const uint32_t* oldToNewPerm)
+{
+  if (m->fmt != 1 || m->C != 64 || m->nChunks == 0) return;
+  const char* env = getenv("SB_PACK");
+  const int want  = env ? atoi(env) : 2; // 0 off, 1 columns only, 2 columns + values
+  if (want <= 0) return;
+  // 1. value dictionary (<= 256 distinct bit patterns, +0.0 always present for padding)
+  std::vector<unsigned long long> dict;
+  dict.push_back(0ull);
+  bool dictOk = want >= 2;
+  if (dictOk) {
+    unsigned long long last = 0ull;
+    for (size_t i = 0; i < m->nElems; i++) {
+      unsigned long long b;
+      memcpy(&b, hostVal + i, 8);
+      if (b == last) continue;
+      last = b;
+      if (std::find(dict.begin(), dict.end(), b) == dict.end()) {
+        dict.push_back(b);
+        if (dict.size() > 256) {
+          dictOk = false;
+          break;
+        }
+      }
+    }
+  }
+  std::sort(dict.begin(), dict.end());
+  m->nDict  = dictOk ? (int)dict.size() : 0;
+  m->padCol = (m->permuted && oldToNewPerm && m->nr) ? oldToNewPerm[0] : 0u;
+  // 2. per-chunk column range on the device
+  uint32_t *cmin = nullptr, *cmax = nullptr;
+  HIP_CHECK(hipMalloc(&cmin, (size_t)m->nChunks * sizeof(uint32_t)));
+  HIP_CHECK(hipMalloc(&cmax, (size_t)m->nChunks * sizeof(uint32_t)));
+  const dim3 grid((m->nChunks + 3) / 4), block(256);
+  hipLaunchKernelGGL(pack_minmax_k, grid, block, 0, g.stream, m->chunkPtr, m->chunkLens, m->colInd, m->val,
+      m->nChunks, m->padCol, cmin, cmax);
+  HIP_CHECK(hipGetLastError());
+  std::vector<uint32_t> lo(m->nChunks), hi(m->nChunks), lens(m->nChunks);
+  sb_d2h(lo.data(), cmin, lo.size() * sizeof(uint32_t));
+  sb_d2h(hi.data(), cmax, hi.size() * sizeof(uint32_t));
+  sb_d2h(lens.data(), m->chunkLens, lens.size() * sizeof(uint32_t));
+  HIP_CHECK(hipFree(cmin));
+  HIP_CHECK(hipFree(cmax));
+  // 3. stream positions
+  std::vector<PackMeta> meta(m->nChunks);
+  uint64_t grp = 0, units = 0;
+  m->nWideChunks = 0;
+  for (uint32_t c = 0; c < m->nChunks; c++) {
+    const bool empty = lo[c] > hi[c];
+    const bool wide  = !empty && (hi[c] - lo[c]) >= 0xFFFFu;
+    const uint32_t ng = (lens[c] + 3u) / 4u;
+    meta[c].grp    = (uint32_t)grp;
+    meta[c].idxOff = (uint32_t)units;
+    meta[c].base   = empty ? 0u : lo[c];
+    meta[c].info   = lens[c] | (wide ? 0x80000000u : 0u);
+    grp += ng;
+    units += (uint64_t)ng * (wide ? 2u : 1u);
+    m->nWideChunks += wide;
+  }
+  if (grp > 0xFFFFFFFFull || units > 0xFFFFFFFFull) return; // does not fit the 32-bit positions
+  m->pmeta = (PackMeta*)upload(meta.data(), meta.size() * sizeof(PackMeta));
+  HIP_CHECK(hipMalloc(&m->pidx, (size_t)units * 512 + 1024));
+  unsigned long long* dbits = nullptr;
+  if (m->nDict) {
+    HIP_CHECK(hipMalloc(&m->pcodes, (size_t)grp * 256 + 1024));
+    std::vector<unsigned long long> padded(256, 0ull);
+    std::copy(dict.begin(), dict.end(), padded.begin());
+    dbits    = (unsigned long long*)upload(dict.data(), dict.size() * sizeof(unsigned long long));
+    m->pdict = (double*)upload(padded.data(), 256 * sizeof(double));
+  }
+  hipLaunchKernelGGL(pack_write_k, grid, block, 0, g.stream, m->chunkPtr, m->chunkLens, m->colInd, m->val,
+      m->pmeta, dbits, m->nDict, m->nChunks, m->padCol, m->pidx, m->pcodes);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  if (dbits) HIP_CHECK(hipFree(dbits));
+  m->packLevel   = m->nDict ? 2 : 1;
+  m->usePacked   = 1;
+  m->packedBytes = (double)units * 512.0 + (m->nDict ? (double)grp * 256.0 : 8.0 * m->nElems) +
+                   16.0 * m->nChunks;
+}
+
+// Level 3 of the compressed mirror: per tile (4 chunks = one workgroup) the contiguous
+// column ranges its rows touch, so the kernel can stage them in LDS (pack.hip.h).
+// Host arrays are the reference-layout ones (columns in ORIGINAL numbering).
+static void build_lds_windows(sb_matrix* m, const uint32_t* chunkPtr, const uint32_t* chunkLens,
+    const uint32_t* colInd, const double* val, const uint32_t* oldToNewPerm)
+{
+  if (m->packLevel < 1) return;
+  const char* env = getenv("SB_PACK");
+  if ((env ? atoi(env) : 3) < 3) return;
+  const uint32_t WMAX = 6144, MERGE_GAP = 8; // window <= 48 KiB of LDS per workgroup
+  const uint32_t nTiles = (m->nChunks + 3) / 4;
+  std::vector<uint32_t> segPtr(nTiles + 1, 0);
+  std::vector<TileSeg> segs;
+  std::vector<uint32_t> cols;
+  std::vector<uint64_t> bitmap;
+  uint32_t maxWin = 0;
+  for (uint32_t t = 0; t < nTiles; t++) {
+    cols.clear();
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+    for (uint32_t c = t * 4; c < std::min(t * 4 + 4, m->nChunks); c++) {
+      const size_t cp = chunkPtr[c];
+      const size_t n  = (size_t)chunkLens[c] * 64;
+      for (size_t e = 0; e < n; e++) {
+        uint32_t col = colInd[cp + e];
+        unsigned long long bits;
+        memcpy(&bits, val + cp + e, 8);
+        if (col == 0 && bits == 0) continue; // padding (or an explicit 0.0 at column 0): slot 0
+        if (m->permuted && col < m->nr) col = oldToNewPerm[col];
+        cols.push_back(col);
+        lo = std::min(lo, col), hi = std::max(hi, col);
+      }
+    }
+    segPtr[t] = (uint32_t)segs.size();
+    if (cols.empty()) continue;
+    // distinct columns in ascending order: bitmap when the span is modest, sort otherwise
+    const uint64_t span = (uint64_t)hi - lo + 1;
+    uint32_t win = 1; // slot 0
+    auto emit = [&](uint32_t first, uint32_t last) {
+      TileSeg s;
+      s.col = first, s.len = last - first + 1, s.lds = win, s.pad_ = 0;
+      win += s.len;
+      segs.push_back(s);
+    };
+    if (span <= (1u << 22)) {
+      bitmap.assign((span + 63) / 64, 0ull);
+      for (uint32_t c : cols) bitmap[(c - lo) >> 6] |= 1ull << ((c - lo) & 63);
+      bool open = false;
+      uint32_t first = 0, last = 0;
+      for (uint64_t w = 0; w < bitmap.size(); w++) {
+        uint64_t bits = bitmap[w];
+        while (bits) {
+          const uint32_t c = lo + (uint32_t)(w * 64 + (uint64_t)__builtin_ctzll(bits));
+          bits &= bits - 1;
+          if (!open) first = last = c, open = true;
+          else if (c - last <= MERGE_GAP) last = c;
+          else emit(first, last), first = last = c;
+        }
+      }
+      if (open) emit(first, last);
+    } else {
+      std::sort(cols.begin(), cols.end());
+      uint32_t first = cols[0], last = cols[0];
+      for (uint32_t c : cols) {
+        if (c - last <= MERGE_GAP) last = std::max(last, c);
+        else emit(first, last), first = last = c;
+      }
+      emit(first, last);
+    }
+    if (win > WMAX) return; // some tile's window does not fit LDS: stay at level 1/2
+    maxWin = std::max(maxWin, win);
+  }
+  segPtr[nTiles] = (uint32_t)segs.size();
+  if (maxWin == 0) maxWin = 1;
+  TileSeg dummy = { 0, 0, 0, 0 };
+  if (segs.empty()) segs.push_back(dummy);
+  m->tileSegPtr = (uint32_t*)upload(segPtr.data(), segPtr.size() * sizeof(uint32_t));
+  m->tileSegs   = (TileSeg*)upload(segs.data(), segs.size() * sizeof(TileSeg));
+  std::vector<PackMeta> meta(m->nChunks);
+  sb_d2h(meta.data(), m->pmeta, meta.size() * sizeof(PackMeta));
+  const uint64_t groups = meta.empty() ? 0 : (uint64_t)meta.back().grp + ((meta.back().info & 0x7FFFFFFFu) + 3u) / 4u;
+  HIP_CHECK(hipMalloc(&m->pslots, (size_t)groups * 512 + 1024));
+  hipLaunchKernelGGL(pack_slots_k, dim3(nTiles), dim3(256), 0, g.stream, m->chunkPtr, m->chunkLens, m->colInd,
+      m->val, m->pmeta, m->tileSegPtr, m->tileSegs, m->nChunks, m->padCol, m->pslots);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  m->ldsWindow = maxWin;
+  m->slotBytes = (double)groups * 512.0 + (m->nDict ? (double)groups * 256.0 : 8.0 * m->nElems) +
+                 16.0 * m->nChunks + 16.0 * segs.size() + 4.0 * nTiles;
+  m->usePacked = 2; // 2: packed stream + x window in LDS
+}
+
 sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, uint32_t nChunks,
     uint32_t nElems, const uint32_t* chunkPtr, const uint32_t* chunkLens, const uint32_t* colInd,
     const double* val, const uint32_t* oldToNewPerm, const uint32_t* newToOldPerm)
@@ -401,6 +594,8 @@ sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, u
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(g.stream));
   }
+  build_packed(m, val, oldToNewPerm);
+  build_lds_windows(m, chunkPtr, chunkLens, colInd, val, oldToNewPerm);
   return m;
 }
 
@@ -409,7 +604,25 @@ void sb_matrix_free(sb_matrix* m)
   if (!m) return;
   sb_free(m->rowPtr), sb_free(m->rowBlocks), sb_free(m->chunkPtr), sb_free(m->chunkLens);
   sb_free(m->oldToNew), sb_free(m->newToOld), sb_free(m->colInd), sb_free(m->val);
+  sb_free(m->pmeta), sb_free(m->pidx), sb_free(m->pcodes), sb_free(m->pdict);
+  sb_free(m->tileSegPtr), sb_free(m->tileSegs), sb_free(m->pslots);
   delete m;
+}
+
+int sb_matrix_pack_level(const sb_matrix* m) { return m->packLevel; }
+void sb_matrix_use_packed(sb_matrix* m, int mode)
+{ // 0 reference-layout stream, 1 packed stream + gathers through the cache, 2 packed + LDS window
+  if (mode >= 2 && m->ldsWindow) m->usePacked = 2;
+  else if (mode >= 1 && m->packLevel) m->usePacked = 1;
+  else m->usePacked = 0;
+}
+int sb_matrix_packed_mode(const sb_matrix* m) { return m->usePacked; }
+uint32_t sb_matrix_lds_window(const sb_matrix* m) { return m->ldsWindow; }
+double sb_matrix_stream_bytes(const sb_matrix* m)
+{ // bytes the SELECTED SpMV kernel moves per launch (matrix stream + x once + y once)
+  if (m->fmt == 1 && m->usePacked == 2) return m->slotBytes + 8.0 * m->nrPadded + 8.0 * m->nc;
+  if (m->fmt == 1 && m->usePacked) return m->packedBytes + 8.0 * m->nrPadded + 8.0 * m->nc;
+  return sb_matrix_spmv_bytes(m);
 }
 uint32_t sb_matrix_nr(const sb_matrix* m) { return m->nr; }
 uint32_t sb_matrix_nc(const sb_matrix* m) { return m->nc; }
@@ -452,6 +665,70 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
     const uint32_t nBlocks = (m->nChunks + 3) / 4;
     const uint32_t per     = g_scs_xcd ? (nBlocks + 7) / 8 : 0;
     dim3 grid(g_scs_xcd ? per * 8 : nBlocks), block(256);
+    if (m->usePacked == 2) {
+      const size_t shmem = (256 + (size_t)m->ldsWindow) * sizeof(double);
+#define LDS_LAUNCH(DI, DO)                                                                              \
+  hipLaunchKernelGGL((spmv_scs64_lds<DI, DO>), grid, block, shmem, g.stream, m->pmeta, m->pslots, m->pcodes, \
+      m->pdict, m->chunkPtr, m->val, m->tileSegPtr, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol,    \
+      dotPartials, stop)
+      if (m->nDict > 0) {
+        if (dotPartials) LDS_LAUNCH(true, true);
+        else LDS_LAUNCH(true, false);
+      } else {
+        if (dotPartials) LDS_LAUNCH(false, true);
+        else LDS_LAUNCH(false, false);
+      }
+#undef LDS_LAUNCH
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+    if (m->usePacked) {
+#define PK_LAUNCH(DI, DO)                                                                              \
+  hipLaunchKernelGGL((spmv_scs64_packed<DI, DO>), grid, block, 0, g.stream, m->pmeta, m->pidx, m->pcodes, \
+      m->pdict, m->chunkPtr, m->val, x, y, m->nr, m->nChunks, per, m->padCol, dotPartials, stop)
+#define PKB_LAUNCH(DI, DO, GBN)                                                                        \
+  hipLaunchKernelGGL((spmv_scs64_packed_b<DI, DO, GBN>), grid, block, 0, g.stream, m->pmeta, m->pidx,  \
+      m->pcodes, m->pdict, m->chunkPtr, m->val, x, y, m->nr, m->nChunks, per, m->padCol, dotPartials, stop)
+#define PKB_PICK(GBN)                                                              \
+  do {                                                                             \
+    if (m->nDict > 0) { if (dotPartials) PKB_LAUNCH(true, true, GBN); else PKB_LAUNCH(true, false, GBN); }   \
+    else { if (dotPartials) PKB_LAUNCH(false, true, GBN); else PKB_LAUNCH(false, false, GBN); }                   \
+  } while (0)
+      static int gb = -1;
+      if (gb < 0) {
+        const char* e = getenv("SB_PACK_GB");
+        gb            = e ? atoi(e) : 0; // 0: simple loop (fastest measured, full occupancy)
+      }
+#define PKC_LAUNCH(DI, DO, SGN)                                                                        \
+  hipLaunchKernelGGL((spmv_scs64_packed_c<DI, DO, SGN>), grid, block, 0, g.stream, m->pmeta, m->pidx,  \
+      m->pcodes, m->pdict, m->chunkPtr, m->val, x, y, m->nr, m->nChunks, per, m->padCol, dotPartials, stop)
+#define PKC_PICK(SGN)                                                              \
+  do {                                                                             \
+    if (m->nDict > 0) { if (dotPartials) PKC_LAUNCH(true, true, SGN); else PKC_LAUNCH(true, false, SGN); }   \
+    else { if (dotPartials) PKC_LAUNCH(false, true, SGN); else PKC_LAUNCH(false, false, SGN); }                   \
+  } while (0)
+      switch (gb) {
+      case 104: PKC_PICK(4); break;
+      case 108: PKC_PICK(8); break;
+      case 2: PKB_PICK(2); break;
+      case 4: PKB_PICK(4); break;
+      case 7: PKB_PICK(7); break;
+      case 8: PKB_PICK(8); break;
+      default:
+        if (m->nDict > 0) {
+          if (dotPartials) PK_LAUNCH(true, true);
+          else PK_LAUNCH(true, false);
+        } else {
+          if (dotPartials) PK_LAUNCH(false, true);
+          else PK_LAUNCH(false, false);
+        }
+      }
+#undef PKB_PICK
+#undef PKB_LAUNCH
+#undef PK_LAUNCH
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
 #define SCS_LAUNCH(U, D, N)                                                                      \
   hipLaunchKernelGGL((spmv_scs64<U, D, N>), grid, block, 0, g.stream, m->chunkPtr, m->chunkLens, \
       m->colInd, m->val, x, y, m->nr, m->nChunks, per, dotPartials, stop)

@@ -49,7 +49,7 @@ static void stage_out(staged_vec* s, double* host, size_t n)
 
 /* ---- kernels with the reference's names ---------------------------------------------- */
 void waxpby(const CG_UINT n, const CG_FLOAT alpha, const CG_FLOAT* restrict x, const CG_FLOAT beta,
-    const CG_FLOAT* restrict y, CG_FLOAT* restrict w)
+    const CG_FLOAT* restrict y, CG_FLOAT* w)
 {
   staged_vec sx = stage_in(x, n, 1);
   staged_vec sy = (y == x) ? sx : stage_in(y, n, 1);

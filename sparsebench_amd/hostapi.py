@@ -131,7 +131,21 @@ class Problem:
         return self.H.sbh_problem_setup_seconds(self.ptr)
 
     def spmv_bytes(self):
+        """algorithmic bytes of one SpMV in the reference's layout"""
         return capi.load().sb_matrix_spmv_bytes(self.matrix)
+
+    def stream_bytes(self):
+        """bytes the selected kernel really moves (compressed mirror, if in use)"""
+        return capi.load().sb_matrix_stream_bytes(self.matrix)
+
+    def use_packed(self, mode):
+        capi.load().sb_matrix_use_packed(self.matrix, int(mode))
+        return capi.load().sb_matrix_packed_mode(self.matrix)
+
+    def pack_info(self):
+        L = capi.load()
+        return {"level": L.sb_matrix_pack_level(self.matrix), "mode": L.sb_matrix_packed_mode(self.matrix),
+                "lds_window_doubles": L.sb_matrix_lds_window(self.matrix)}
 
     def free(self):
         if self.ptr:

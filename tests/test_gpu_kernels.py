@@ -32,9 +32,21 @@ def upload_scs(L, s):
 
 
 def gpu_spmv(L, m, x, nr):
+    """y = A x through the C-ABI; when the matrix has a compressed mirror, BOTH kernels
+    (packed stream and reference-layout stream) must give the same bits"""
     dx, dy = DeviceVector.from_host(x), DeviceVector(nr)
     L.sb_spmv(m, dx.ptr, dy.ptr)
     y = dy.get()
+    if L.sb_matrix_pack_level(m) > 0:
+        best = L.sb_matrix_packed_mode(m)
+        assert best == (2 if L.sb_matrix_lds_window(m) else 1)
+        for mode in (0, 1, 2):  # reference stream / packed + cache gathers / packed + LDS window
+            L.sb_matrix_use_packed(m, mode)
+            dy.set(np.full(nr, 7.0))
+            L.sb_spmv(m, dx.ptr, dy.ptr)
+            y2 = dy.get()
+            assert np.array_equal(y.view(np.uint64), y2.view(np.uint64)), "kernel mode %d differs" % mode
+        L.sb_matrix_use_packed(m, best)
     dx.free(), dy.free()
     return y
 
@@ -113,6 +125,49 @@ def test_spmv_ragged_random_and_long_rows(gpu):
             m = upload_scs(L, s)
             assert np.array_equal(gpu_spmv(L, m, x, nr), y), ("scs", nr, Cc, sg)
             L.sb_matrix_free(m)
+
+
+def test_packed_stream_levels_and_wide_chunks(gpu):
+    """the lossless compressed mirror: dictionary on/off, 16-bit and 32-bit (wide) chunks,
+    padding marker, sigma > 1 (renumbered padding column), chunk widths 0..9 mod 4"""
+    L = gpu
+    rng = np.random.default_rng(23)
+    # (a) few distinct values + banded columns -> level 2, narrow
+    g = po.GMatrix.generate(9, 8, 7)
+    for sg in (1, 64, 4096):
+        s = g.to_scs(64, sg)
+        m = upload_scs(L, s)
+        assert L.sb_matrix_pack_level(m) == 2
+        x = rng.standard_normal(g.nc)
+        assert np.array_equal(gpu_spmv(L, m, x, g.nr), g.spmv(x))
+        assert L.sb_matrix_stream_bytes(m) < 0.45 * L.sb_matrix_spmv_bytes(m)
+        L.sb_matrix_free(m)
+    # (b) random values (no dictionary) + columns spread over a huge range -> level 1, wide chunks
+    for nr, nc, maxlen in ((700, 300000, 11), (129, 70000, 5), (64, 65535, 3), (64, 65536 + 64, 4)):
+        gm = random_csr(rng, nr, nc, maxlen)
+        x = rng.standard_normal(nc)
+        for sg in (1, 128):
+            s = gm.to_scs(64, sg)
+            m = upload_scs(L, s)
+            distinct = len(np.unique(np.concatenate([gm.val, [0.0]]).view(np.uint64)))
+            assert L.sb_matrix_pack_level(m) == (2 if distinct <= 256 else 1)
+            assert np.array_equal(gpu_spmv(L, m, x, nr), gm.spmv(x)), (nr, nc, sg)
+            L.sb_matrix_free(m)
+    # (c) exactly 256 / 257 distinct values: dictionary boundary; explicit zeros and -0.0 kept
+    for nvals, level in ((255, 2), (256, 1)):  # +0.0 for padding is always in the dictionary
+        nr = 400
+        rp = np.arange(0, 3 * nr + 1, 3, dtype=np.uint32)
+        col = rng.integers(0, nr, size=3 * nr).astype(np.uint32)
+        pool = np.concatenate([np.arange(1, nvals - 1, dtype=np.float64) * 0.37, [-0.0, np.inf]])[:nvals]
+        val = pool[np.arange(3 * nr) % nvals]
+        gm = po.GMatrix.from_csr(rp, col, val, nc=nr)
+        s = gm.to_scs(64, 1)
+        m = upload_scs(L, s)
+        assert L.sb_matrix_pack_level(m) == level, (nvals, L.sb_matrix_pack_level(m))
+        x = rng.standard_normal(nr)
+        got, exp = gpu_spmv(L, m, x, nr), gm.spmv(x)
+        assert np.array_equal(got.view(np.uint64), exp.view(np.uint64))
+        L.sb_matrix_free(m)
 
 
 def test_spmv_empty_matrix(gpu):

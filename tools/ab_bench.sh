@@ -10,5 +10,6 @@ for v in "$@"; do
   env $v python bench.py --no-cpu "${extra[@]}" | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('it/s=%.0f ms/step=%.4f spmv_us=%.1f GB/s=%.0f' % (d['value'], d['ms_per_step'], r['avg_launch_us'], r['achieved']))"
+q=d.get('roofline_reference_layout')
+print('it/s=%.0f ms/step=%.4f spmv_us=%.1f GB/s=%.0f moved=%.0fGB/s %s' % (d['value'], d['ms_per_step'], r['avg_launch_us'], r['achieved'], r.get('moved_GBs',0), ('| ref-layout: %.1fus %.0fGB/s %.0fit/s' % (q['avg_launch_us'], q['achieved'], q['cg_iterations_per_s'])) if q else ''))"
 done
