@@ -212,7 +212,34 @@ __global__ __launch_bounds__(256) void spmv_scs_generic(const uint32_t* __restri
 // A row longer than the tile is walked tile by tile by thread 0 (still in order).
 // =============================================================================
 constexpr int CRS_THREADS = 256;
-constexpr int CRS_TILE    = 4096; // nonzeros per LDS tile (32 KiB)
+constexpr int CRS_TILE    = 2048; // nonzeros per LDS tile (16 KiB: 8 workgroups per CU)
+constexpr int CRS_BATCH   = CRS_TILE / CRS_THREADS; // products per thread per tile
+
+// products of nonzeros [base, end) -> prod[]: all of a thread's loads are issued before
+// the first use (stream loads, then gathers), one HBM + one cache round trip per tile
+__device__ __forceinline__ void crs_products(uint32_t base, uint32_t end, uint32_t t,
+    const uint32_t* __restrict__ colInd, const double* __restrict__ val, const double* __restrict__ x,
+    double* prod)
+{
+  double v[CRS_BATCH], xv[CRS_BATCH];
+  uint32_t c[CRS_BATCH];
+#pragma unroll
+  for (int u = 0; u < CRS_BATCH; u++) {
+    const uint32_t k = base + t + (uint32_t)u * CRS_THREADS;
+    v[u] = 0.0, c[u] = 0u;
+    if (k < end) v[u] = stream_load(val + k), c[u] = stream_load(colInd + k);
+  }
+#pragma unroll
+  for (int u = 0; u < CRS_BATCH; u++) {
+    const uint32_t k = base + t + (uint32_t)u * CRS_THREADS;
+    xv[u]            = k < end ? x[c[u]] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < CRS_BATCH; u++) {
+    const uint32_t k = base + t + (uint32_t)u * CRS_THREADS;
+    if (k < end) prod[k - base] = v[u] * xv[u];
+  }
+}
 
 __global__ __launch_bounds__(CRS_THREADS) void spmv_crs_stream(
     const uint32_t* __restrict__ rowBlocks, const uint32_t* __restrict__ rowPtr,
@@ -221,19 +248,19 @@ __global__ __launch_bounds__(CRS_THREADS) void spmv_crs_stream(
     uint32_t blocksPerXcd, const int* __restrict__ stop)
 {
   __shared__ double prod[CRS_TILE];
-  if (stop && *stop) return;
+  const int stopped = stop ? *stop : 0;
   const uint32_t lb = xcd_block(blockIdx.x, blocksPerXcd);
-  if (lb >= nBlocks) return;
+  if (lb >= nBlocks || stopped) return;
   const uint32_t r0 = rowBlocks[lb], r1 = rowBlocks[lb + 1];
   const uint32_t n0 = rowPtr[r0], n1 = rowPtr[r1];
   const uint32_t t = threadIdx.x;
   if (n1 - n0 <= (uint32_t)CRS_TILE) {
-    for (uint32_t k = n0 + t; k < n1; k += CRS_THREADS)
-      prod[k - n0] = stream_load(val + k) * x[stream_load(colInd + k)];
+    const uint32_t r = r0 + t; // this thread's row (if any): fetch its extent early
+    uint32_t a = 0, b = 0;
+    if (r < r1) a = rowPtr[r] - n0, b = rowPtr[r + 1] - n0;
+    crs_products(n0, n1, t, colInd, val, x, prod);
     __syncthreads();
-    const uint32_t r = r0 + t;
     if (r < r1) {
-      const uint32_t a = rowPtr[r] - n0, b = rowPtr[r + 1] - n0;
       double sum = 0.0;
       for (uint32_t k = a; k < b; k++) sum = sum + prod[k];
       y[r] = sum;
@@ -243,8 +270,7 @@ __global__ __launch_bounds__(CRS_THREADS) void spmv_crs_stream(
     for (uint32_t base = n0; base < n1; base += CRS_TILE) {
       const uint32_t end = min(base + (uint32_t)CRS_TILE, n1);
       __syncthreads();
-      for (uint32_t k = base + t; k < end; k += CRS_THREADS)
-        prod[k - base] = stream_load(val + k) * x[stream_load(colInd + k)];
+      crs_products(base, end, t, colInd, val, x, prod);
       __syncthreads();
       if (t == 0)
         for (uint32_t k = 0; k < end - base; k++) sum = sum + prod[k];

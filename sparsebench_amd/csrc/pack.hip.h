@@ -381,10 +381,34 @@ __global__ __launch_bounds__(256) void spmv_scs64_lds(const PackMeta* __restrict
   extern __shared__ __attribute__((aligned(16))) double lds[]; // [256 dict][window]
   double* sdict = lds;
   double* sx    = lds + 256;
+  constexpr int PF = 8; // groups prefetched before the window is staged (a 32-column chunk)
   const int stopped   = stop ? *stop : 0;
   const uint32_t tile = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
   const uint32_t nTiles = (nChunks + 3u) >> 2;
   if (tile >= nTiles || stopped) return; // uniform per workgroup
+  const uint32_t chunk = __builtin_amdgcn_readfirstlane(tile * 4u + (threadIdx.x >> 6));
+  const uint32_t lane  = threadIdx.x & 63u;
+  const bool active    = chunk < nChunks; // wave-uniform; inactive waves still help staging
+  PackMeta m           = { 0u, 0u, 0u, 0u };
+  if (active) m = meta[chunk];
+  const uint32_t cpv = (DICT || !active) ? 0u : chunkPtr[chunk];
+  const uint32_t len = m.info & 0x7FFFFFFFu;
+  const uint32_t ng  = (len + 3u) >> 2;
+  const u32x2* sstream    = reinterpret_cast<const u32x2*>(slots) + (size_t)m.grp * 64 + lane;
+  const uint32_t* cstream = codes + (size_t)m.grp * 64 + lane;
+  const double* vraw      = val + cpv + lane;
+  // 1. the chunk's slot/code stream goes in flight first (HBM latency) ...
+  u32x2 iv[PF];
+  uint32_t cw[PF];
+#pragma unroll
+  for (int gi = 0; gi < PF; gi++) {
+    iv[gi] = u32x2{ 0u, 0u }, cw[gi] = 0u;
+    if ((uint32_t)gi < ng) {
+      iv[gi] = stream_load(sstream + (size_t)gi * 64);
+      if (DICT) cw[gi] = stream_load(cstream + (size_t)gi * 64);
+    }
+  }
+  // 2. ... while the workgroup stages its x window (mostly L2 hits)
   if (DICT) sdict[threadIdx.x] = dict[threadIdx.x];
   if (threadIdx.x == 0) sx[0] = x[padCol]; // slot 0: what padding multiplies (src/matrix-SCS.c:151-155)
   const uint32_t s0 = tileSegPtr[tile], s1 = tileSegPtr[tile + 1];
@@ -393,42 +417,32 @@ __global__ __launch_bounds__(256) void spmv_scs64_lds(const PackMeta* __restrict
     for (uint32_t i = threadIdx.x; i < sg.len; i += 256u) sx[sg.lds + i] = x[sg.col + i];
   }
   __syncthreads();
-  const uint32_t chunk = __builtin_amdgcn_readfirstlane(tile * 4u + (threadIdx.x >> 6));
-  const uint32_t lane  = threadIdx.x & 63u;
-  if (chunk >= nChunks) return;
-  const PackMeta m   = meta[chunk];
-  const uint32_t cpv = DICT ? 0u : chunkPtr[chunk];
-  const uint32_t len = m.info & 0x7FFFFFFFu;
-  const uint32_t nFull = len >> 2, rem = len & 3u;
-  const u32x2* sstream    = reinterpret_cast<const u32x2*>(slots) + (size_t)m.grp * 64 + lane;
-  const uint32_t* cstream = codes + (size_t)m.grp * 64 + lane;
-  const double* vraw      = val + cpv + lane;
-  double acc              = 0.0;
-  uint32_t g              = 0;
-  for (; g + 2 <= nFull; g += 2) {
-    const u32x2 i0 = stream_load(sstream + (size_t)g * 64);
-    const u32x2 i1 = stream_load(sstream + (size_t)(g + 1) * 64);
-    uint32_t cw0 = 0, cw1 = 0;
-    if (DICT) cw0 = stream_load(cstream + (size_t)g * 64), cw1 = stream_load(cstream + (size_t)(g + 1) * 64);
-    const uint32_t d[8] = { i0.x & 0xFFFFu, i0.x >> 16, i0.y & 0xFFFFu, i0.y >> 16,
-                            i1.x & 0xFFFFu, i1.x >> 16, i1.y & 0xFFFFu, i1.y >> 16 };
+  if (!active) return;
+  // 3. accumulate left to right: x from LDS, values from the dictionary or the fp64 stream
+  double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const uint32_t cw = k < 4 ? cw0 : cw1;
-      const double vv   = DICT ? sdict[(cw >> (8u * (k & 3))) & 255u]
-                               : stream_load(vraw + (size_t)((g + (k >> 2)) * 4u + (k & 3)) * 64);
-      acc = acc + vv * sx[d[k]];
+  for (int gi = 0; gi < PF; gi++) {
+    if ((uint32_t)gi < ng) {
+      const uint32_t d[4] = { iv[gi].x & 0xFFFFu, iv[gi].x >> 16, iv[gi].y & 0xFFFFu, iv[gi].y >> 16 };
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t j = (uint32_t)gi * 4u + k;
+        if (j < len) {
+          const double vv = DICT ? sdict[(cw[gi] >> (8u * k)) & 255u] : stream_load(vraw + (size_t)j * 64);
+          acc             = acc + vv * sx[d[k]];
+        }
+      }
     }
   }
-  for (; g < nFull + (rem ? 1u : 0u); g++) {
+  for (uint32_t g = PF; g < ng; g++) { // chunks wider than 32 columns
     const u32x2 i0      = stream_load(sstream + (size_t)g * 64);
-    const uint32_t cw   = DICT ? stream_load(cstream + (size_t)g * 64) : 0u;
+    const uint32_t cw0  = DICT ? stream_load(cstream + (size_t)g * 64) : 0u;
     const uint32_t d[4] = { i0.x & 0xFFFFu, i0.x >> 16, i0.y & 0xFFFFu, i0.y >> 16 };
-    const uint32_t kmax = g < nFull ? 4u : rem;
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
-      if (k < kmax) { // wave-uniform
-        const double vv = DICT ? sdict[(cw >> (8u * k)) & 255u] : stream_load(vraw + (size_t)(g * 4u + k) * 64);
+      const uint32_t j = g * 4u + k;
+      if (j < len) {
+        const double vv = DICT ? sdict[(cw0 >> (8u * k)) & 255u] : stream_load(vraw + (size_t)j * 64);
         acc             = acc + vv * sx[d[k]];
       }
     }
