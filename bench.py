@@ -194,7 +194,8 @@ def main():
         while left > 0:
             seg = min(left, SEGMENT)
             cg.spmv_timing(False)
-            cg.solve(itermax=W + 2, eps=0.0)  # prologue + W+1 bodies: warm-up, untimed
+            cg.start(itermax=W + 2 + seg, eps=0.0)  # prologue
+            cg.run_iters(W + 1)                     # warm-up bodies, untimed
             before = cg.counters()
             cg.spmv_timing(with_spmv_events)
             barrier()
@@ -203,7 +204,10 @@ def main():
             barrier()
             dt = time.perf_counter() - t0
             after = cg.counters()
-            if after["stop"] or after["n_pAp"] - before["n_pAp"] != seg or after["n_rr"] - before["n_rr"] != seg:
+            cg.finish()
+            if after["stop"] and after["iters"] != W + 1 + seg:
+                raise RuntimeError("bench: the loop exited early: %r" % after)
+            if after["n_pAp"] - before["n_pAp"] != seg or after["iters"] != W + 1 + seg:
                 raise RuntimeError("bench: the timed iterations did not all execute: %r -> %r" % (before, after))
             if with_spmv_events:
                 ms, cnt = cg.spmv_ms()

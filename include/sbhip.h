@@ -111,7 +111,9 @@ void sb_waxpby(uint32_t n, double alpha, const double* x, double beta, const dou
  * Fixed summation order (DESIGN.md "dot order"): bit-reproducible run to run. */
 void sb_ddot_async(uint32_t n, const double* x, const double* y, double* result_dev);
 double sb_ddot(uint32_t n, const double* x, const double* y); /* synchronises */
-/* the two stages of the fixed order, exposed for parity tests */
+/* the stages of the fixed order, exposed for parity tests: level 0 writes one partial per
+ * 64 elements into partials_dev[0 .. 4*ceil(n/256)) (tail zeroed); sb_reduce_final does
+ * levels 1-2 over m = ceil(n/256) groups of four partials */
 void sb_ddot_partials(uint32_t n, const double* x, const double* y, double* partials_dev);
 void sb_reduce_final(uint32_t m, const double* partials_dev, double* result_dev);
 
@@ -158,9 +160,14 @@ void sb_cg_set_graph(sb_cg* s, int use_graph);
 /* Runs solveCG's whole loop without host synchronisation; returns k exactly as
  * the reference does (src/CGSolver.c:140).  Blocking. */
 int sb_cg_solve(sb_cg* s, int itermax, double eps);
-/* Enqueue `iters` more loop bodies (k >= 2 shape) on the stream without touching
- * the host: what bench.py times.  sb_cg_solve(…,2,…) must have run first. */
+/* The same in three steps, for callers that time a slice of the loop (bench.py):
+ *   sb_cg_start      x0 = 0, prologue (src/CGSolver.c:94-103), loop test for k = 1; enqueues only
+ *   sb_cg_run_iters  enqueue the next `iters` loop bodies (k = 1, 2, ...); never touches the host;
+ *                    bodies past the reference's loop exit (k >= itermax or normr <= eps) are no-ops
+ *   sb_cg_finish     wait and return k as solveCG does                                        */
+void sb_cg_start(sb_cg* s, int itermax, double eps);
 void sb_cg_run_iters(sb_cg* s, int iters);
+int sb_cg_finish(sb_cg* s);
 /* every r.r (index 0 = prologue) and p.Ap the solve produced, full precision */
 int sb_cg_history(const sb_cg* s, double* rr_out, int rr_cap, double* pAp_out, int pAp_cap,
                   int* n_pAp);

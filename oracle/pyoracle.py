@@ -257,7 +257,7 @@ def ddot_tree(x, y):
 
 
 def ddot_partials(x, y):
-    q = np.empty((len(x) + 63) // 64, dtype=np.float64)
+    q = np.empty((len(x) + 255) // 256, dtype=np.float64)
     lib().orc_ddot_partials(len(x), _p(x), _p(y), _p(q))
     return q
 

@@ -581,27 +581,34 @@ double orc_ddot_seq(uint32_t n, const double* x, const double* y)
 }
 
 /* Canonical reduction order of the HIP kernels (DESIGN.md "dot order").
- * Level 0: every aligned group of 64 consecutive elements is reduced by an
- * xor butterfly with offsets 1,2,4,8,16,32 (what 64 lanes do with shuffles);
- * missing tail elements count as +0.0. */
-void orc_ddot_partials(uint32_t n, const double* x, const double* y, double* partials)
+ * Level 0: every aligned group of 64 consecutive elements is reduced by an xor
+ * butterfly with offsets 1,2,4,8,16,32 (what 64 lanes do with shuffles).
+ * Level 1: every aligned group of four such groups (256 elements) is added left to
+ * right, ((g0+g1)+g2)+g3 -> one partial per 256 elements (what one workgroup of four
+ * wavefronts does).  Missing tail elements / groups count as +0.0. */
+static double group64(uint32_t g, uint32_t n, const double* x, const double* y)
 {
-  uint32_t m = (n + 63) / 64;
-  for (uint32_t g = 0; g < m; g++) {
-    double v[64], t[64];
-    for (uint32_t l = 0; l < 64; l++) {
-      uint32_t i = g * 64 + l;
-      v[l]       = i < n ? x[i] * y[i] : 0.0;
-    }
-    for (uint32_t off = 1; off < 64; off <<= 1) {
-      for (uint32_t l = 0; l < 64; l++) t[l] = v[l] + v[l ^ off];
-      memcpy(v, t, sizeof v);
-    }
-    partials[g] = v[0];
+  double v[64], t[64];
+  for (uint32_t l = 0; l < 64; l++) {
+    uint64_t i = (uint64_t)g * 64 + l;
+    v[l]       = i < n ? x[i] * y[i] : 0.0;
   }
+  for (uint32_t off = 1; off < 64; off <<= 1) {
+    for (uint32_t l = 0; l < 64; l++) t[l] = v[l] + v[l ^ off];
+    memcpy(v, t, sizeof v);
+  }
+  return v[0];
 }
 
-/* Level 1: one workgroup of 1024 threads; thread t sums partials t, t+1024, ...
+void orc_ddot_partials(uint32_t n, const double* x, const double* y, double* partials)
+{
+  uint32_t m = (n + 255) / 256;
+  for (uint32_t q = 0; q < m; q++)
+    partials[q] = ((group64(4 * q, n, x, y) + group64(4 * q + 1, n, x, y)) + group64(4 * q + 2, n, x, y)) +
+                  group64(4 * q + 3, n, x, y);
+}
+
+/* Level 2: 1024 (virtual) threads; thread t sums partials t, t+1024, ...
  * sequentially; each wave of 64 threads butterflies (1..32); the 16 wave sums
  * are added in wave order. */
 double orc_reduce_final(uint32_t m, const double* q)
@@ -627,7 +634,7 @@ double orc_reduce_final(uint32_t m, const double* q)
 
 double orc_ddot_tree(uint32_t n, const double* x, const double* y)
 {
-  uint32_t m = (n + 63) / 64;
+  uint32_t m = (n + 255) / 256;
   double* q  = (double*)xmalloc((size_t)(m + 1) * sizeof(double));
   orc_ddot_partials(n, x, y, q);
   double r = orc_reduce_final(m, q);

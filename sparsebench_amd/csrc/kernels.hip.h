@@ -4,22 +4,23 @@
 // with -ffp-contract=off): per element the results are bit-identical to the
 // reference's strict-IEEE CPU loops, and dot products use ONE fixed summation
 // order (DESIGN.md "dot order") so they are reproducible and can be restated on
-// the CPU (oracle/sb_oracle.c: orc_ddot_partials / orc_reduce_final).
+// the CPU by the test oracle.
 //
-// Everything here is HBM-bandwidth bound (0.16 flop/byte): no MFMA; the levers
-// are coalesced 512 B..1 KiB wave-instructions, enough loads in flight per CU,
-// keeping the gathered vector in the XCD-local L2, and fusing reductions into the
-// kernel that already holds the operands.
+// Nothing here is a dense contraction (0.16 flop/byte): no MFMA.  The levers are
+// coalesced 256 B..1 KiB wave-instructions, bytes in flight per CU, x kept in the
+// XCD-local L2 / in LDS, few bytes per nonzero (pack.hip.h), and few launches: dots are
+// fused into the kernels that already hold their operands.  (Finishing a reduction INSIDE
+// its producer -- last-arriving workgroup, sharded tickets -- was built and measured: every
+// workgroup then ends on a store drain + returning atomic, SpMV 50 -> 71 us for 12 us of
+// launches saved.  Removed; see DESIGN.md.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace sbk {
 
-constexpr int WAVE = 64;
-
-// Control block shared by the CG kernels (lives in HBM, never read by the host
-// inside the loop).
+// Control block of the CG loop (lives in HBM; the host writes it once per solve and
+// reads it once at the end).
 struct CgScalars {
   double rr;      // rtrans          (src/CGSolver.c:83)
   double rr_old;  // oldrtrans
@@ -27,19 +28,21 @@ struct CgScalars {
   double alpha;   // rtrans / pAp    (:126)
   double beta;    // rtrans / oldrtrans (:113)
   double neg_alpha;
-  double local;   // rank-local sum handed to the all-reduce
-  double pad;
-  int stop;       // 1: the reference's loop has exited; every kernel returns
-  int stop_next;  // !(normr > eps) as of the last r.r (loop condition, :107)
-  int iters;      // last k whose body ran
-  int n_rr;       // entries in rr_hist
+  double local;   // rank-local sum handed to / returned by the all-reduce
+  double eps;
+  int stop;       // 1: the reference's for loop has exited; every kernel returns
+  int stop_next;  // !(normr > eps) for the normr the NEXT loop test will see (:107,:116)
+  int iters;      // k of the last loop body that runs / ran
+  int n_rr;       // entries written to rr_hist
   int n_pAp;
-  int pad2[3];
+  int itermax;
+  int hist_cap;
+  int pad;
 };
 
 // ---- wave-level fixed-order reductions --------------------------------------
 // xor butterfly, offsets 1,2,4,...: every lane ends with the same value because
-// fp add is commutative.  This IS the level-0 order of the canonical dot.
+// fp add is commutative.  This IS level 0 of the canonical dot.
 __device__ __forceinline__ double butterfly64(double v)
 {
 #pragma unroll
@@ -68,51 +71,92 @@ template <typename T> __device__ __forceinline__ T stream_load(const T* p)
 }
 
 // =============================================================================
-// Sell-C-sigma SpMV, C = 64: one wavefront per chunk, lane k = row k of the chunk
-// (reference loop: src/matrix-SCS.c:208-227, its inner k loop is our lane axis).
-// val/colInd are column-major inside the chunk, so each wave-instruction reads
-// 512 B of val and 256 B of colInd, fully coalesced.  Each lane accumulates its
-// row left to right exactly like the CPU loop.  DOT fuses p.Ap (level 0 of the
-// canonical order: chunk i == 64-group i of the output vector).
+// The canonical dot ("dot order")
+//   level 0   every aligned group of 64 consecutive elements: xor butterfly (above)
+//             -> one partial per 64 elements, written by the producing kernel
+//             (in SpMV: one per chunk, by the wave that owns the chunk);
+//   level 1   every aligned group of 4 partials (256 elements): ((q0+q1)+q2)+q3;
+//   level 2   1024 threads: thread t adds level-1 values t, t+1024, ... in order; each
+//             wave butterflies; the 16 wave sums are added in wave order.
+// Levels 1 and 2 run in ONE workgroup (reduce_final_1024); level 1 exists so that a
+// thread's inputs are 32 contiguous bytes (two 16-B loads instead of four 8-B loads).
+// Missing tail elements / partials count as +0.0: the partial array always holds
+// 4*ceil(n/256) entries and producers zero the tail.
 // =============================================================================
-template <int UNROLL, bool DOT, bool NT>
-__global__ __launch_bounds__(256) void spmv_scs64(const uint32_t* __restrict__ chunkPtr,
-    const uint32_t* __restrict__ chunkLens, const uint32_t* __restrict__ colInd,
-    const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
-    uint32_t nr, uint32_t nChunks, uint32_t blocksPerXcd, double* __restrict__ dotPartials,
-    const int* __restrict__ stop)
+__device__ __forceinline__ double level1(const double* __restrict__ q, uint32_t i)
 {
-  const int stopped    = stop ? *stop : 0; // one wait covers this and the loads below
-  const uint32_t lb    = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
-  const uint32_t chunk = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
-  const uint32_t lane  = threadIdx.x & 63u;
-  if (chunk >= nChunks) return;
-  const uint32_t cp  = chunkPtr[chunk];
-  const uint32_t len = chunkLens[chunk];
-  if (stopped) return;
-  const double* v    = val + cp + lane;
-  const uint32_t* c  = colInd + cp + lane;
-  double acc         = 0.0;
-  uint32_t j         = 0;
-  for (; j + UNROLL <= len; j += UNROLL) {
-    double vv[UNROLL];
-    uint32_t cc[UNROLL];
-    double xx[UNROLL];
+  const double2 a = *reinterpret_cast<const double2*>(q + 4u * (size_t)i);
+  const double2 b = *reinterpret_cast<const double2*>(q + 4u * (size_t)i + 2u);
+  return ((a.x + a.y) + b.x) + b.y;
+}
+
+// m = number of level-1 values = ceil(n/256); q holds 4*m level-0 partials
+__device__ __forceinline__ double reduce_final_1024(uint32_t m, const double* __restrict__ q,
+    double* lds16)
+{
+  double s   = 0.0;
+  uint32_t i = threadIdx.x;
+  for (; i + 7u * 1024u < m; i += 8u * 1024u) { // 16 independent 16-B loads in flight
+    double a[8];
 #pragma unroll
-    for (int u = 0; u < UNROLL; u++) {
-      vv[u] = NT ? stream_load(v + (size_t)(j + u) * 64) : v[(size_t)(j + u) * 64];
-      cc[u] = NT ? stream_load(c + (size_t)(j + u) * 64) : c[(size_t)(j + u) * 64];
+    for (int u = 0; u < 8; u++) a[u] = level1(q, i + (uint32_t)u * 1024u);
+#pragma unroll
+    for (int u = 0; u < 8; u++) s = s + a[u];
+  }
+  for (; i < m; i += 1024u) s = s + level1(q, i);
+  s = butterfly64(s);
+  if ((threadIdx.x & 63u) == 0) lds16[threadIdx.x >> 6] = s;
+  __syncthreads();
+  double total = lds16[0];
+#pragma unroll
+  for (int w = 1; w < 16; w++) total = total + lds16[w];
+  return total; // every thread returns the same value
+}
+
+// The scalar steps of solveCG.  MODE 0: r.r of the prologue (src/CGSolver.c:98-103) and the
+// loop test for k = 1.  MODE 1: the loop test for the next k (:107), and if it passes
+// the r.r / beta of that iteration (:111-113,:116).  MODE 2: p.Ap -> alpha (:124-126).
+template <int MODE>
+__device__ __forceinline__ void cg_apply(CgScalars* S, double total, double* rr_hist,
+    double* pAp_hist)
+{
+  if (MODE == 0) {
+    const int sn = !(sqrt(total) > S->eps);
+    S->rr        = total;
+    S->stop_next = sn;
+    if (S->n_rr < S->hist_cap) rr_hist[S->n_rr] = total;
+    S->n_rr++;
+    if (1 < S->itermax && !sn) S->iters = 1;
+    else S->stop = 1;
+  } else if (MODE == 1) {
+    if (S->iters + 1 < S->itermax && !S->stop_next) {
+      const double old = S->rr;
+      S->rr_old        = old;
+      S->rr            = total;
+      S->beta          = total / old;
+      S->stop_next     = !(sqrt(total) > S->eps);
+      S->iters         = S->iters + 1;
+      if (S->n_rr < S->hist_cap) rr_hist[S->n_rr] = total;
+      S->n_rr++;
+    } else {
+      S->stop = 1;
     }
-#pragma unroll
-    for (int u = 0; u < UNROLL; u++) xx[u] = x[cc[u]];
-#pragma unroll
-    for (int u = 0; u < UNROLL; u++) acc = acc + vv[u] * xx[u];
+  } else {
+    S->pAp          = total;
+    const double al = S->rr / total;
+    S->alpha        = al;
+    S->neg_alpha    = -al;
+    if (S->n_pAp < S->hist_cap) pAp_hist[S->n_pAp] = total;
+    S->n_pAp++;
   }
-  for (; j < len; j++) {
-    double vv   = NT ? stream_load(v + (size_t)j * 64) : v[(size_t)j * 64];
-    uint32_t cc = NT ? stream_load(c + (size_t)j * 64) : c[(size_t)j * 64];
-    acc         = acc + vv * x[cc];
-  }
+}
+
+// SpMV epilogue: y store and, when DOT, the chunk's level-0 partial of p.Ap (a chunk IS a
+// 64-group of the output vector).  No barrier: each wave finishes on its own.
+template <bool DOT>
+__device__ __forceinline__ void spmv_epilogue(uint32_t chunk, uint32_t lane, double acc,
+    const double* __restrict__ x, double* __restrict__ y, uint32_t nr, double* __restrict__ dotPartials)
+{
   const uint32_t row = chunk * 64u + lane;
   if (row < nr) y[row] = acc;
   if (DOT) {
@@ -122,64 +166,57 @@ __global__ __launch_bounds__(256) void spmv_scs64(const uint32_t* __restrict__ c
   }
 }
 
-// Software-pipelined form of the same kernel.  A wave streams its chunk in batches of
-// U columns; the val/colInd loads of batch b+1 are issued right after the x-gathers
-// of batch b, so the HBM latency of the stream overlaps the L2 latency of the gather
-// instead of adding to it.  Loads may run up to U-1 columns past the chunk's end (the
-// arrays carry SCS_SLACK elements of zero padding, and a following chunk's indices
-// are valid columns); such columns are never accumulated.  Same per-row order, same
-// bits as spmv_scs64.
-constexpr uint32_t SCS_SLACK = 16 * 64;
+// =============================================================================
+// Sell-C-sigma SpMV, C = 64, reference layout: one wavefront per chunk, lane k = row
+// k of the chunk (reference loop: src/matrix-SCS.c:208-227, its inner k loop is our
+// lane axis).  val/colInd are column-major inside the chunk, so each wave-instruction
+// reads 512 B of val and 256 B of colInd, fully coalesced.  Each lane accumulates its
+// row left to right exactly like the CPU loop.
+// =============================================================================
+constexpr uint32_t SCS_SLACK = 16 * 64; // zeroed elements behind val / colInd
 
-template <int U, bool DOT>
-__global__ __launch_bounds__(256) void spmv_scs64_pipe(const uint32_t* __restrict__ chunkPtr,
+template <int UNROLL, bool DOT, bool NT>
+__global__ __launch_bounds__(256) void spmv_scs64(const uint32_t* __restrict__ chunkPtr,
     const uint32_t* __restrict__ chunkLens, const uint32_t* __restrict__ colInd,
     const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y,
     uint32_t nr, uint32_t nChunks, uint32_t blocksPerXcd, double* __restrict__ dotPartials,
     const int* __restrict__ stop)
 {
-  const int stopped    = stop ? *stop : 0; // issued together with the loads below
-  const uint32_t lb    = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
+  const int stopped      = stop ? *stop : 0; // one wait covers this and the loads below
+  const uint32_t nBlocks = (nChunks + 3u) >> 2;
+  const uint32_t lb      = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
+  if (lb >= nBlocks || stopped) return; // uniform per workgroup
   const uint32_t chunk = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
   const uint32_t lane  = threadIdx.x & 63u;
   if (chunk >= nChunks) return;
-  const uint32_t cp  = chunkPtr[chunk];
-  const uint32_t len = chunkLens[chunk];
-  if (stopped) return;
-  const double* v   = val + cp + lane;
-  const uint32_t* c = colInd + cp + lane;
-  double acc        = 0.0;
-  double va[U], vb[U];
-  uint32_t ca[U], cb[U];
+  double acc = 0.0;
+  {
+    const uint32_t cp  = chunkPtr[chunk];
+    const uint32_t len = chunkLens[chunk];
+    const double* v    = val + cp + lane;
+    const uint32_t* c  = colInd + cp + lane;
+    uint32_t j         = 0;
+    for (; j + UNROLL <= len; j += UNROLL) {
+      double vv[UNROLL];
+      uint32_t cc[UNROLL];
+      double xx[UNROLL];
 #pragma unroll
-  for (int u = 0; u < U; u++) {
-    va[u] = stream_load(v + (size_t)u * 64);
-    ca[u] = stream_load(c + (size_t)u * 64);
-  }
-  for (uint32_t j = 0; j < len; j += U) {
-    double xx[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) xx[u] = x[ca[u]];
-    if (j + U < len) {
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        vb[u] = stream_load(v + (size_t)(j + U + u) * 64);
-        cb[u] = stream_load(c + (size_t)(j + U + u) * 64);
+      for (int u = 0; u < UNROLL; u++) {
+        vv[u] = NT ? stream_load(v + (size_t)(j + u) * 64) : v[(size_t)(j + u) * 64];
+        cc[u] = NT ? stream_load(c + (size_t)(j + u) * 64) : c[(size_t)(j + u) * 64];
       }
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) xx[u] = x[cc[u]];
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) acc = acc + vv[u] * xx[u];
     }
-#pragma unroll
-    for (int u = 0; u < U; u++)
-      if (j + u < len) acc = acc + va[u] * xx[u];
-#pragma unroll
-    for (int u = 0; u < U; u++) va[u] = vb[u], ca[u] = cb[u];
+    for (; j < len; j++) {
+      double vv   = NT ? stream_load(v + (size_t)j * 64) : v[(size_t)j * 64];
+      uint32_t cc = NT ? stream_load(c + (size_t)j * 64) : c[(size_t)j * 64];
+      acc         = acc + vv * x[cc];
+    }
   }
-  const uint32_t row = chunk * 64u + lane;
-  if (row < nr) y[row] = acc;
-  if (DOT) {
-    double t = row < nr ? x[row] * acc : 0.0;
-    t        = butterfly64(t);
-    if (lane == 0) dotPartials[chunk] = t;
-  }
+  spmv_epilogue<DOT>(chunk, lane, acc, x, y, nr, dotPartials);
 }
 
 // Any C (the reference's fixtures use C = 1, 2, 4): one thread per padded row.
@@ -352,168 +389,97 @@ __global__ __launch_bounds__(256) void cg_update_p(uint32_t n, const double* __r
   }
 }
 
-// Level 0 of the canonical dot: partials[g] = butterfly over elements 64g..64g+63.
-// A wave covers 128 elements per step with 16-B loads: lane l holds elements
-// 2l, 2l+1; its in-lane add is butterfly offset 1, lane-xor 1..16 are offsets
-// 2..32; lanes 0-31 own group 2s, lanes 32-63 group 2s+1.
-__device__ __forceinline__ void dot_span(uint32_t span, uint32_t n, const double* x,
-    const double* y, double* partials, uint32_t lane)
-{
-  const uint32_t e = span * 128u + lane * 2u;
-  double t         = 0.0;
-  if (e + 1 < n) {
-    const double2 a = *reinterpret_cast<const double2*>(x + e);
-    const double2 b = *reinterpret_cast<const double2*>(y + e);
-    t               = a.x * b.x + a.y * b.y;
-  } else if (e < n) {
-    t = x[e] * y[e] + 0.0;
-  }
-  t = butterfly32(t);
-  const uint32_t g = span * 2u + (lane >> 5);
-  if ((lane & 31u) == 0 && g * 64u < n) partials[g] = t;
-}
-
-__global__ __launch_bounds__(256) void ddot_partials_k(uint32_t n, const double* x,
-    const double* y, double* __restrict__ partials, const int* __restrict__ stop)
+// ---- dot-producing vector kernels -------------------------------------------------------
+// A wave covers a "span" of 128 consecutive elements per step with 16-B loads: lane l
+// holds elements 2l, 2l+1 (its in-lane add is butterfly offset 1, lane-xor 1..16 are
+// offsets 2..32), so lanes 0-31 / 32-63 produce the level-0 partials 2s / 2s+1.  Spans
+// beyond n write +0.0 so the partial array is complete up to 4*ceil(n/256).
+// OP 0: dot(a, b)                                       (ddot, src/solver.c:41-62)
+// OP 1: x += alpha p ; r -= alpha Ap ; dot(r, r)        (src/CGSolver.c:127-128 + :112)
+// OP 2: r = b - Ap ; dot(r, r)                          (src/CGSolver.c:97-98)
+template <int OP>
+__global__ __launch_bounds__(256) void dot_spans_k(uint32_t n, const double* a, const double* b,
+    double* x, double* r, const CgScalars* __restrict__ S, double* __restrict__ partials,
+    const int* __restrict__ stop)
 {
   if (stop && *stop) return;
   const uint32_t lane   = threadIdx.x & 63u;
-  const uint32_t nSpans = (n + 127u) >> 7;
+  const uint32_t nSpans = ((n + 255u) >> 8) * 2u; // whole 256-groups
   const uint32_t nWaves = gridDim.x * (blockDim.x >> 6);
-  for (uint32_t s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < nSpans; s += nWaves)
-    dot_span(s, n, x, y, partials, lane);
-}
-
-// x += alpha p ; r -= alpha Ap ; partials of the NEW r.r  (src/CGSolver.c:127-128
-// and the ddot of :112 of the next iteration) in one pass: 4 streams in, 2 out.
-__global__ __launch_bounds__(256) void cg_update_xr_dot(uint32_t n, double* x,
-    const double* __restrict__ p, double* r, const double* __restrict__ Ap,
-    const CgScalars* __restrict__ S, double* __restrict__ partials)
-{
-  if (S->stop) return;
-  const double alpha    = S->alpha;
-  const double nalpha   = -alpha;
-  const uint32_t lane   = threadIdx.x & 63u;
-  const uint32_t nSpans = (n + 127u) >> 7;
-  const uint32_t nWaves = gridDim.x * (blockDim.x >> 6);
+  double alpha = 0.0, nalpha = 0.0;
+  if (OP == 1) alpha = S->alpha, nalpha = -alpha;
   for (uint32_t s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < nSpans; s += nWaves) {
     const uint32_t e = s * 128u + lane * 2u;
     double t         = 0.0;
-    if (e + 1 < n) {
-      double2 xv        = *reinterpret_cast<double2*>(x + e);
-      const double2 pv  = *reinterpret_cast<const double2*>(p + e);
-      double2 rv        = *reinterpret_cast<double2*>(r + e);
-      const double2 av  = *reinterpret_cast<const double2*>(Ap + e);
-      xv.x = xv.x + alpha * pv.x;
-      xv.y = xv.y + alpha * pv.y;
-      rv.x = rv.x + nalpha * av.x;
-      rv.y = rv.y + nalpha * av.y;
-      *reinterpret_cast<double2*>(x + e) = xv;
-      *reinterpret_cast<double2*>(r + e) = rv;
-      t = rv.x * rv.x + rv.y * rv.y;
-    } else if (e < n) {
-      x[e]            = x[e] + alpha * p[e];
-      const double rn = r[e] + nalpha * Ap[e];
-      r[e]            = rn;
-      t               = rn * rn + 0.0;
+    if (OP == 0) {
+      if (e + 1 < n) {
+        const double2 av = *reinterpret_cast<const double2*>(a + e);
+        const double2 bv = *reinterpret_cast<const double2*>(b + e);
+        t                = av.x * bv.x + av.y * bv.y;
+      } else if (e < n) {
+        t = a[e] * b[e] + 0.0;
+      }
+    } else if (OP == 1) { // a = p, b = Ap
+      if (e + 1 < n) {
+        double2 xv       = *reinterpret_cast<double2*>(x + e);
+        const double2 pv = *reinterpret_cast<const double2*>(a + e);
+        double2 rv       = *reinterpret_cast<double2*>(r + e);
+        const double2 av = *reinterpret_cast<const double2*>(b + e);
+        xv.x = xv.x + alpha * pv.x;
+        xv.y = xv.y + alpha * pv.y;
+        rv.x = rv.x + nalpha * av.x;
+        rv.y = rv.y + nalpha * av.y;
+        *reinterpret_cast<double2*>(x + e) = xv;
+        *reinterpret_cast<double2*>(r + e) = rv;
+        t = rv.x * rv.x + rv.y * rv.y;
+      } else if (e < n) {
+        x[e]            = x[e] + alpha * a[e];
+        const double rn = r[e] + nalpha * b[e];
+        r[e]            = rn;
+        t               = rn * rn + 0.0;
+      }
+    } else { // a = b (rhs), b = Ap
+      if (e + 1 < n) {
+        const double2 bv = *reinterpret_cast<const double2*>(a + e);
+        const double2 av = *reinterpret_cast<const double2*>(b + e);
+        double2 rv;
+        rv.x = bv.x + -1.0 * av.x;
+        rv.y = bv.y + -1.0 * av.y;
+        *reinterpret_cast<double2*>(r + e) = rv;
+        t = rv.x * rv.x + rv.y * rv.y;
+      } else if (e < n) {
+        const double rn = a[e] + -1.0 * b[e];
+        r[e]            = rn;
+        t               = rn * rn + 0.0;
+      }
     }
     t = butterfly32(t);
-    const uint32_t g = s * 2u + (lane >> 5);
-    if ((lane & 31u) == 0 && g * 64u < n) partials[g] = t;
+    if ((lane & 31u) == 0) partials[s * 2u + (lane >> 5)] = t;
   }
 }
 
-// r = b - Ap with the r.r partials fused (prologue, src/CGSolver.c:97-98)
-__global__ __launch_bounds__(256) void cg_residual_dot(uint32_t n, const double* __restrict__ b,
-    const double* __restrict__ Ap, double* __restrict__ r, double* __restrict__ partials)
-{
-  const uint32_t lane   = threadIdx.x & 63u;
-  const uint32_t nSpans = (n + 127u) >> 7;
-  const uint32_t nWaves = gridDim.x * (blockDim.x >> 6);
-  for (uint32_t s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < nSpans; s += nWaves) {
-    const uint32_t e = s * 128u + lane * 2u;
-    double t         = 0.0;
-    if (e + 1 < n) {
-      const double2 bv = *reinterpret_cast<const double2*>(b + e);
-      const double2 av = *reinterpret_cast<const double2*>(Ap + e);
-      double2 rv;
-      rv.x = bv.x + -1.0 * av.x;
-      rv.y = bv.y + -1.0 * av.y;
-      *reinterpret_cast<double2*>(r + e) = rv;
-      t = rv.x * rv.x + rv.y * rv.y;
-    } else if (e < n) {
-      const double rn = b[e] + -1.0 * Ap[e];
-      r[e]            = rn;
-      t               = rn * rn + 0.0;
-    }
-    t = butterfly32(t);
-    const uint32_t g = s * 2u + (lane >> 5);
-    if ((lane & 31u) == 0 && g * 64u < n) partials[g] = t;
-  }
-}
-
-// Level 1 of the canonical dot: ONE workgroup of 1024 threads.  Thread t adds
-// partials t, t+1024, ... in order; each wave butterflies; the 16 wave sums are
-// added in wave order by thread 0.
-__device__ __forceinline__ double reduce_final_block(uint32_t m, const double* __restrict__ q,
-    double* lds16)
-{
-  double s   = 0.0;
-  uint32_t i = threadIdx.x;
-  // same order as the plain loop, but 32 / 8 independent loads are in flight at a time
-  // (the partials were written by other CUs: every load is an L2/fabric round trip,
-  // and this single workgroup sits on the critical path of every CG iteration)
-  for (; i + 31u * 1024u < m; i += 32u * 1024u) {
-    double a[32];
-#pragma unroll
-    for (int u = 0; u < 32; u++) a[u] = q[i + (uint32_t)u * 1024u];
-#pragma unroll
-    for (int u = 0; u < 32; u++) s = s + a[u];
-  }
-  for (; i + 7u * 1024u < m; i += 8u * 1024u) {
-    double a[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) a[u] = q[i + (uint32_t)u * 1024u];
-#pragma unroll
-    for (int u = 0; u < 8; u++) s = s + a[u];
-  }
-  for (; i < m; i += 1024u) s = s + q[i];
-  s = butterfly64(s);
-  if ((threadIdx.x & 63u) == 0) lds16[threadIdx.x >> 6] = s;
-  __syncthreads();
-  double total = lds16[0];
-#pragma unroll
-  for (int w = 1; w < 16; w++) total = total + lds16[w];
-  return total; // every thread returns the same value
-}
-
+// stand-alone level 2 (sb_reduce_final / unfused path)
 __global__ __launch_bounds__(1024) void reduce_final_k(uint32_t m, const double* __restrict__ q,
     double* __restrict__ out, const int* __restrict__ stop)
 {
   __shared__ double lds16[16];
   if (stop && *stop) return;
-  const double total = reduce_final_block(m, q, lds16);
+  const double total = reduce_final_1024(m, q, lds16);
   if (threadIdx.x == 0) *out = total;
 }
 
-// CG scalar steps.  MODE: 0 prologue r.r, 1 loop r.r (top of iteration k >= 2),
-// 2 p.Ap.  When REDUCE is false the (all-reduced) sum is already in S->local.
+// CG scalar step as its own launch: the reference-shaped (unfused) path, and after the
+// all-reduce on several ranks (REDUCE = false: the sum is already in S->local).
 template <int MODE, bool REDUCE>
 __global__ __launch_bounds__(1024) void cg_scalar_k(uint32_t m, const double* __restrict__ q,
-    CgScalars* S, double eps, double* __restrict__ rr_hist, double* __restrict__ pAp_hist,
-    int hist_cap, int to_local_only)
+    CgScalars* S, double* __restrict__ rr_hist, double* __restrict__ pAp_hist, int to_local)
 {
   __shared__ double lds16[16];
   if (S->stop) return;
-  if (MODE == 1 && S->stop_next) { // the reference's `normr > eps` test failed: loop exits
-    __syncthreads();
-    if (threadIdx.x == 0) S->stop = 1;
-    return;
-  }
   double total;
   if (REDUCE) {
-    total = reduce_final_block(m, q, lds16);
-    if (to_local_only) { // multi-rank: hand the local sum to the all-reduce
+    total = reduce_final_1024(m, q, lds16);
+    if (to_local) {
       if (threadIdx.x == 0) S->local = total;
       return;
     }
@@ -521,37 +487,7 @@ __global__ __launch_bounds__(1024) void cg_scalar_k(uint32_t m, const double* __
     total = S->local;
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  if (MODE == 0) {
-    S->rr        = total;
-    S->stop_next = !(sqrt(total) > eps);
-    if (S->n_rr < hist_cap) rr_hist[S->n_rr] = total;
-    S->n_rr++;
-  } else if (MODE == 1) {
-    const double old = S->rr;
-    S->rr_old        = old;
-    S->rr            = total;
-    S->beta          = total / old;
-    S->stop_next     = !(sqrt(total) > eps);
-    S->iters         = S->iters + 1;
-    if (S->n_rr < hist_cap) rr_hist[S->n_rr] = total;
-    S->n_rr++;
-  } else {
-    S->pAp          = total;
-    const double al = S->rr / total;
-    S->alpha        = al;
-    S->neg_alpha    = -al;
-    if (S->n_pAp < hist_cap) pAp_hist[S->n_pAp] = total;
-    S->n_pAp++;
-  }
-}
-
-// top of iteration k == 1 (no r.r there): apply the loop condition
-__global__ void cg_iter1_begin(CgScalars* S)
-{
-  if (S->stop) return;
-  if (S->stop_next) S->stop = 1;
-  else S->iters = 1;
+  if (threadIdx.x == 0) cg_apply<MODE>(S, total, rr_hist, pAp_hist);
 }
 
 // =============================================================================
@@ -563,13 +499,6 @@ __global__ __launch_bounds__(256) void gather_k(uint32_t n, const uint32_t* __re
   if (stop && *stop) return;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[idx[i]];
-}
-
-__global__ __launch_bounds__(256) void scatter_k(uint32_t n, const uint32_t* __restrict__ idx,
-    const double* __restrict__ in, double* __restrict__ out)
-{ // out[idx[i]] = in[i]
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[idx[i]] = in[i];
 }
 
 __global__ __launch_bounds__(256) void max_abs_diff_partials(uint32_t n,

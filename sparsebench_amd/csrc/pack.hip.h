@@ -118,7 +118,10 @@ __global__ __launch_bounds__(256) void pack_write_k(const uint32_t* __restrict__
 
 // ---- SpMV on the packed stream --------------------------------------------------------
 // One wavefront per chunk, lane = row, exactly as spmv_scs64; per group of four columns
-// a lane issues one index load, one code load (DICT) and four x gathers.
+// a lane issues one index load, one code load (DICT) and four x gathers.  Two groups
+// (eight columns) are kept in flight.  (Deeper batching / prefetching variants were
+// measured slower: they cost occupancy, and the limiter is the gather instruction rate
+// of the vector cache, not the length of the dependency chain.)
 template <bool DICT, bool DOT>
 __global__ __launch_bounds__(256) void spmv_scs64_packed(const PackMeta* __restrict__ meta,
     const uint32_t* __restrict__ idx, const uint32_t* __restrict__ codes,
@@ -128,186 +131,71 @@ __global__ __launch_bounds__(256) void spmv_scs64_packed(const PackMeta* __restr
     const int* __restrict__ stop)
 {
   __shared__ double sdict[256];
+  const int stopped      = stop ? *stop : 0;
+  const uint32_t nBlocks = (nChunks + 3u) >> 2;
+  const uint32_t lb      = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
+  if (lb >= nBlocks || stopped) return; // uniform per workgroup
   if (DICT) {
     sdict[threadIdx.x] = dict[threadIdx.x];
     __syncthreads();
   }
-  const int stopped    = stop ? *stop : 0;
-  const uint32_t lb    = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
   const uint32_t chunk = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
   const uint32_t lane  = threadIdx.x & 63u;
-  if (chunk >= nChunks) return;
-  const PackMeta m   = meta[chunk];
-  const uint32_t cpv = DICT ? 0u : chunkPtr[chunk];
-  if (stopped) return;
-  const uint32_t len = m.info & 0x7FFFFFFFu;
-  const bool wide    = m.info >> 31;
-  const uint32_t nFull = len >> 2, rem = len & 3u;
-  const uint32_t* cstream = codes + (size_t)m.grp * 64 + lane;
-  const double* vraw      = val + cpv + lane;
-  double acc              = 0.0;
-
-#define SB_ACCUM(G, K, COL)                                                              \
-  do {                                                                                   \
-    const double xv_ = x[COL];                                                           \
-    const double vv_ = DICT ? sdict[(cw >> (8u * (K))) & 255u]                           \
-                            : stream_load(vraw + (size_t)((G) * 4u + (K)) * 64);         \
-    acc = acc + vv_ * xv_;                                                               \
-  } while (0)
-
-  if (!wide) {
-    const u32x2* istream = reinterpret_cast<const u32x2*>(idx) + (size_t)m.idxOff * 64 + lane;
-    uint32_t g = 0;
-    for (; g + 2 <= nFull; g += 2) { // 8 columns in flight
-      const u32x2 i0 = stream_load(istream + (size_t)g * 64);
-      const u32x2 i1 = stream_load(istream + (size_t)(g + 1) * 64);
-      uint32_t cw0 = 0, cw1 = 0;
-      if (DICT) cw0 = stream_load(cstream + (size_t)g * 64), cw1 = stream_load(cstream + (size_t)(g + 1) * 64);
-      uint32_t d[8] = { i0.x & 0xFFFFu, i0.x >> 16, i0.y & 0xFFFFu, i0.y >> 16,
-                        i1.x & 0xFFFFu, i1.x >> 16, i1.y & 0xFFFFu, i1.y >> 16 };
-      double xv[8];
+  const bool active    = chunk < nChunks;
+  double acc           = 0.0;
+  if (active) {
+    const PackMeta m     = meta[chunk];
+    const uint32_t cpv   = DICT ? 0u : chunkPtr[chunk];
+    const uint32_t len   = m.info & 0x7FFFFFFFu;
+    const bool wide      = m.info >> 31;
+    const uint32_t ng    = (len + 3u) >> 2;
+    const uint32_t* cstream = codes + (size_t)m.grp * 64 + lane;
+    const double* vraw      = val + cpv + lane;
+    if (!wide) {
+      const u32x2* istream = reinterpret_cast<const u32x2*>(idx) + (size_t)m.idxOff * 64 + lane;
+      for (uint32_t g = 0; g < ng; g += 2) {
+        const bool two = g + 1 < ng; // wave-uniform
+        const u32x2 i0 = stream_load(istream + (size_t)g * 64);
+        u32x2 i1       = u32x2{ PACK_PAD | (PACK_PAD << 16), PACK_PAD | (PACK_PAD << 16) };
+        uint32_t cw0 = 0, cw1 = 0;
+        if (two) i1 = stream_load(istream + (size_t)(g + 1) * 64);
+        if (DICT) {
+          cw0 = stream_load(cstream + (size_t)g * 64);
+          if (two) cw1 = stream_load(cstream + (size_t)(g + 1) * 64);
+        }
+        const uint32_t d[8] = { i0.x & 0xFFFFu, i0.x >> 16, i0.y & 0xFFFFu, i0.y >> 16,
+                                i1.x & 0xFFFFu, i1.x >> 16, i1.y & 0xFFFFu, i1.y >> 16 };
+        double xv[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) xv[k] = x[d[k] == PACK_PAD ? padCol : m.base + d[k]];
+        for (int k = 0; k < 8; k++) xv[k] = x[d[k] == PACK_PAD ? padCol : m.base + d[k]];
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const uint32_t cw = k < 4 ? cw0 : cw1;
-        const double vv   = DICT ? sdict[(cw >> (8u * (k & 3))) & 255u]
-                                 : stream_load(vraw + (size_t)((g + (k >> 2)) * 4u + (k & 3)) * 64);
-        acc = acc + vv * xv[k];
-      }
-    }
-    for (; g < nFull; g++) {
-      const u32x2 i0    = stream_load(istream + (size_t)g * 64);
-      const uint32_t cw = DICT ? stream_load(cstream + (size_t)g * 64) : 0u;
-      const uint32_t d[4] = { i0.x & 0xFFFFu, i0.x >> 16, i0.y & 0xFFFFu, i0.y >> 16 };
-#pragma unroll
-      for (int k = 0; k < 4; k++) SB_ACCUM(g, k, d[k] == PACK_PAD ? padCol : m.base + d[k]);
-    }
-    if (rem) { // last, partial group: columns beyond the chunk's width are not accumulated
-      const u32x2 i0    = stream_load(istream + (size_t)nFull * 64);
-      const uint32_t cw = DICT ? stream_load(cstream + (size_t)nFull * 64) : 0u;
-      const uint32_t d[4] = { i0.x & 0xFFFFu, i0.x >> 16, i0.y & 0xFFFFu, i0.y >> 16 };
-      for (uint32_t k = 0; k < rem; k++) SB_ACCUM(nFull, k, d[k] == PACK_PAD ? padCol : m.base + d[k]);
-    }
-  } else {
-    const u32x4* istream = reinterpret_cast<const u32x4*>(idx + (size_t)m.idxOff * 128) + lane;
-    for (uint32_t g = 0; g < nFull; g++) {
-      const u32x4 i0    = stream_load(istream + (size_t)g * 64);
-      const uint32_t cw = DICT ? stream_load(cstream + (size_t)g * 64) : 0u;
-      const uint32_t d[4] = { i0.x, i0.y, i0.z, i0.w };
-#pragma unroll
-      for (int k = 0; k < 4; k++) SB_ACCUM(g, k, d[k]);
-    }
-    if (rem) {
-      const u32x4 i0    = stream_load(istream + (size_t)nFull * 64);
-      const uint32_t cw = DICT ? stream_load(cstream + (size_t)nFull * 64) : 0u;
-      const uint32_t d[4] = { i0.x, i0.y, i0.z, i0.w };
-      for (uint32_t k = 0; k < rem; k++) SB_ACCUM(nFull, k, d[k]);
-    }
-  }
-#undef SB_ACCUM
-  const uint32_t row = chunk * 64u + lane;
-  if (row < nr) y[row] = acc;
-  if (DOT) {
-    double t = row < nr ? x[row] * acc : 0.0;
-    t        = butterfly64(t);
-    if (lane == 0) dotPartials[chunk] = t;
-  }
-}
-
-// "One HBM round trip per chunk" form.  PMC of the simple loop shows waves waiting 74 %
-// of their cycles: per chunk it chains ~4 x (stream load -> gather -> accumulate).  Here a
-// wave first fetches the indices/codes of up to SG groups (a whole HPCG chunk: 7 groups,
-// 24 VGPRs) in one burst, then gathers and accumulates eight columns at a time, so the
-// chain is one HBM latency plus a few L1/L2 latencies, at full occupancy (<= 64 VGPRs).
-template <bool DICT, bool DOT, int SG>
-__global__ __launch_bounds__(256) void spmv_scs64_packed_c(const PackMeta* __restrict__ meta,
-    const uint32_t* __restrict__ idx, const uint32_t* __restrict__ codes,
-    const double* __restrict__ dict, const uint32_t* __restrict__ chunkPtr,
-    const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y, uint32_t nr,
-    uint32_t nChunks, uint32_t blocksPerXcd, uint32_t padCol, double* __restrict__ dotPartials,
-    const int* __restrict__ stop)
-{
-  __shared__ double sdict[256];
-  if (DICT) {
-    sdict[threadIdx.x] = dict[threadIdx.x];
-    __syncthreads();
-  }
-  const int stopped    = stop ? *stop : 0;
-  const uint32_t lb    = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
-  const uint32_t chunk = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
-  const uint32_t lane  = threadIdx.x & 63u;
-  if (chunk >= nChunks) return;
-  const PackMeta m   = meta[chunk];
-  const uint32_t cpv = DICT ? 0u : chunkPtr[chunk];
-  if (stopped) return;
-  const uint32_t len      = m.info & 0x7FFFFFFFu;
-  const bool wide         = m.info >> 31;
-  const uint32_t ng       = (len + 3u) >> 2;
-  const uint32_t* cstream = codes + (size_t)m.grp * 64 + lane;
-  const double* vraw      = val + cpv + lane;
-  double acc              = 0.0;
-  if (!wide) {
-    const u32x2* istream = reinterpret_cast<const u32x2*>(idx) + (size_t)m.idxOff * 64 + lane;
-    for (uint32_t b0 = 0; b0 < ng; b0 += SG) {
-      u32x2 iv[SG];
-      uint32_t cw[SG];
-#pragma unroll
-      for (int gi = 0; gi < SG; gi++) {
-        iv[gi] = u32x2{ 0u, 0u }, cw[gi] = 0u;
-        if (b0 + gi < ng) {
-          iv[gi] = stream_load(istream + (size_t)(b0 + gi) * 64);
-          if (DICT) cw[gi] = stream_load(cstream + (size_t)(b0 + gi) * 64);
+        for (int k = 0; k < 8; k++) {
+          const uint32_t j = g * 4u + (uint32_t)k;
+          if (j < len) { // wave-uniform: columns beyond the chunk's width are not accumulated
+            const uint32_t cw = k < 4 ? cw0 : cw1;
+            const double vv   = DICT ? sdict[(cw >> (8u * (k & 3))) & 255u] : stream_load(vraw + (size_t)j * 64);
+            acc               = acc + vv * xv[k];
+          }
         }
       }
+    } else {
+      const u32x4* istream = reinterpret_cast<const u32x4*>(idx + (size_t)m.idxOff * 128) + lane;
+      for (uint32_t g = 0; g < ng; g++) {
+        const u32x4 i0      = stream_load(istream + (size_t)g * 64);
+        const uint32_t cw0  = DICT ? stream_load(cstream + (size_t)g * 64) : 0u;
+        const uint32_t d[4] = { i0.x, i0.y, i0.z, i0.w };
 #pragma unroll
-      for (int s2 = 0; s2 < SG; s2 += 2) {
-        if (b0 + s2 < ng) {
-          double xv[8];
-#pragma unroll
-          for (int q = 0; q < 2; q++) {
-            const u32x2 w       = iv[s2 + q];
-            const uint32_t d[4] = { w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16 };
-#pragma unroll
-            for (int k = 0; k < 4; k++) xv[q * 4 + k] = x[d[k] == PACK_PAD ? padCol : m.base + d[k]];
-          }
-#pragma unroll
-          for (int q = 0; q < 2; q++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const uint32_t j = (b0 + s2 + q) * 4u + k;
-              if (j < len) {
-                const double vv = DICT ? sdict[(cw[s2 + q] >> (8u * k)) & 255u] : stream_load(vraw + (size_t)j * 64);
-                acc             = acc + vv * xv[q * 4 + k];
-              }
-            }
+        for (int k = 0; k < 4; k++) {
+          const uint32_t j = g * 4u + (uint32_t)k;
+          if (j < len) {
+            const double vv = DICT ? sdict[(cw0 >> (8u * k)) & 255u] : stream_load(vraw + (size_t)j * 64);
+            acc             = acc + vv * x[d[k]];
           }
         }
       }
     }
-  } else {
-    const u32x4* istream = reinterpret_cast<const u32x4*>(idx + (size_t)m.idxOff * 128) + lane;
-    for (uint32_t g = 0; g < ng; g++) {
-      const u32x4 i0      = stream_load(istream + (size_t)g * 64);
-      const uint32_t cw0  = DICT ? stream_load(cstream + (size_t)g * 64) : 0u;
-      const uint32_t d[4] = { i0.x, i0.y, i0.z, i0.w };
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t j = g * 4u + k;
-        if (j < len) {
-          const double vv = DICT ? sdict[(cw0 >> (8u * k)) & 255u] : stream_load(vraw + (size_t)j * 64);
-          acc             = acc + vv * x[d[k]];
-        }
-      }
-    }
   }
-  const uint32_t row = chunk * 64u + lane;
-  if (row < nr) y[row] = acc;
-  if (DOT) {
-    double t = row < nr ? x[row] * acc : 0.0;
-    t        = butterfly64(t);
-    if (lane == 0) dotPartials[chunk] = t;
-  }
+  if (active) spmv_epilogue<DOT>(chunk, lane, acc, x, y, nr, dotPartials);
 }
 
 // ---- level 3: the x window of a tile staged in LDS -------------------------------------
@@ -382,8 +270,8 @@ __global__ __launch_bounds__(256) void spmv_scs64_lds(const PackMeta* __restrict
   double* sdict = lds;
   double* sx    = lds + 256;
   constexpr int PF = 8; // groups prefetched before the window is staged (a 32-column chunk)
-  const int stopped   = stop ? *stop : 0;
-  const uint32_t tile = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
+  const int stopped     = stop ? *stop : 0;
+  const uint32_t tile   = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
   const uint32_t nTiles = (nChunks + 3u) >> 2;
   if (tile >= nTiles || stopped) return; // uniform per workgroup
   const uint32_t chunk = __builtin_amdgcn_readfirstlane(tile * 4u + (threadIdx.x >> 6));
@@ -447,115 +335,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_lds(const PackMeta* __restrict
       }
     }
   }
-  const uint32_t row = chunk * 64u + lane;
-  if (row < nr) y[row] = acc;
-  if (DOT) {
-    double t = row < nr ? x[row] * acc : 0.0;
-    t        = butterfly64(t);
-    if (lane == 0) dotPartials[chunk] = t;
-  }
-}
-
-// Batched + prefetching form for narrow chunks.  With 3 bytes per element the kernel is
-// no longer HBM-bound but latency-bound (stream load -> gather -> accumulate per group),
-// so a wave keeps GB groups (4*GB columns) of gathers in flight at once and fetches the
-// next batch's indices/codes while the current gathers are outstanding.  Wide chunks
-// fall back to the simple loop.  Same per-row order and bits.
-template <bool DICT, bool DOT, int GB>
-__global__ __launch_bounds__(256) void spmv_scs64_packed_b(const PackMeta* __restrict__ meta,
-    const uint32_t* __restrict__ idx, const uint32_t* __restrict__ codes,
-    const double* __restrict__ dict, const uint32_t* __restrict__ chunkPtr,
-    const double* __restrict__ val, const double* __restrict__ x, double* __restrict__ y, uint32_t nr,
-    uint32_t nChunks, uint32_t blocksPerXcd, uint32_t padCol, double* __restrict__ dotPartials,
-    const int* __restrict__ stop)
-{
-  __shared__ double sdict[256];
-  if (DICT) {
-    sdict[threadIdx.x] = dict[threadIdx.x];
-    __syncthreads();
-  }
-  const int stopped    = stop ? *stop : 0;
-  const uint32_t lb    = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
-  const uint32_t chunk = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
-  const uint32_t lane  = threadIdx.x & 63u;
-  if (chunk >= nChunks) return;
-  const PackMeta m   = meta[chunk];
-  const uint32_t cpv = DICT ? 0u : chunkPtr[chunk];
-  if (stopped) return;
-  const uint32_t len      = m.info & 0x7FFFFFFFu;
-  const bool wide         = m.info >> 31;
-  const uint32_t ng       = (len + 3u) >> 2;
-  const uint32_t* cstream = codes + (size_t)m.grp * 64 + lane;
-  const double* vraw      = val + cpv + lane;
-  double acc              = 0.0;
-  if (!wide) {
-    const u32x2* istream = reinterpret_cast<const u32x2*>(idx) + (size_t)m.idxOff * 64 + lane;
-    u32x2 iv[GB], ivn[GB];
-    uint32_t cw[GB], cwn[GB];
-#pragma unroll
-    for (int gi = 0; gi < GB; gi++) {
-      iv[gi] = u32x2{ 0u, 0u }, cw[gi] = 0u, ivn[gi] = u32x2{ 0u, 0u }, cwn[gi] = 0u;
-      if ((uint32_t)gi < ng) {
-        iv[gi] = stream_load(istream + (size_t)gi * 64);
-        if (DICT) cw[gi] = stream_load(cstream + (size_t)gi * 64);
-      }
-    }
-    for (uint32_t b = 0; b < ng; b += GB) {
-      double xv[GB * 4];
-#pragma unroll
-      for (int gi = 0; gi < GB; gi++) {
-        if (b + gi < ng) {
-          const uint32_t d[4] = { iv[gi].x & 0xFFFFu, iv[gi].x >> 16, iv[gi].y & 0xFFFFu, iv[gi].y >> 16 };
-#pragma unroll
-          for (int k = 0; k < 4; k++) xv[gi * 4 + k] = x[d[k] == PACK_PAD ? padCol : m.base + d[k]];
-        }
-      }
-#pragma unroll
-      for (int gi = 0; gi < GB; gi++) {
-        if (b + GB + gi < ng) {
-          ivn[gi] = stream_load(istream + (size_t)(b + GB + gi) * 64);
-          if (DICT) cwn[gi] = stream_load(cstream + (size_t)(b + GB + gi) * 64);
-        }
-      }
-#pragma unroll
-      for (int gi = 0; gi < GB; gi++) {
-        if (b + gi < ng) {
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const uint32_t j = (b + gi) * 4u + k;
-            if (j < len) {
-              const double vv = DICT ? sdict[(cw[gi] >> (8u * k)) & 255u] : stream_load(vraw + (size_t)j * 64);
-              acc             = acc + vv * xv[gi * 4 + k];
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int gi = 0; gi < GB; gi++) iv[gi] = ivn[gi], cw[gi] = cwn[gi];
-    }
-  } else {
-    const u32x4* istream = reinterpret_cast<const u32x4*>(idx + (size_t)m.idxOff * 128) + lane;
-    for (uint32_t g = 0; g < ng; g++) {
-      const u32x4 i0      = stream_load(istream + (size_t)g * 64);
-      const uint32_t cw0  = DICT ? stream_load(cstream + (size_t)g * 64) : 0u;
-      const uint32_t d[4] = { i0.x, i0.y, i0.z, i0.w };
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t j = g * 4u + k;
-        if (j < len) {
-          const double vv = DICT ? sdict[(cw0 >> (8u * k)) & 255u] : stream_load(vraw + (size_t)j * 64);
-          acc             = acc + vv * x[d[k]];
-        }
-      }
-    }
-  }
-  const uint32_t row = chunk * 64u + lane;
-  if (row < nr) y[row] = acc;
-  if (DOT) {
-    double t = row < nr ? x[row] * acc : 0.0;
-    t        = butterfly64(t);
-    if (lane == 0) dotPartials[chunk] = t;
-  }
+  spmv_epilogue<DOT>(chunk, lane, acc, x, y, nr, dotPartials);
 }
 
 } // namespace sbk

@@ -210,6 +210,9 @@ struct sb_cg {
   bool spmvTiming;
   std::vector<hipEvent_t> spmvEv;
   size_t spmvEvUsed;
+  int k_next;        // next loop body to enqueue
+  bool started;
+  CgScalars hostS;   // staging copy for the H2D of the control block
 };
 
 // ===========================================================================
@@ -654,14 +657,15 @@ double sb_matrix_spmv_bytes(const sb_matrix* m)
 static int g_scs_unroll = -1;
 static int g_scs_nt     = -1;
 static int g_scs_xcd    = 1;
-static int g_scs_pipe   = 0;
 
+// dotPartials != NULL: fuse the level-0 partials of p.Ap into the SpMV (SCS C=64 only)
 static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* dotPartials,
     const int* stop)
 {
+  const bool dot = dotPartials != nullptr;
   if (m->nr == 0) return;
   if (m->fmt == 0) {
-    if (dotPartials) SB_FATAL("fused dot is an SCS C=64 feature");
+    if (dot) SB_FATAL("fused dot is an SCS C=64 feature");
     const uint32_t per = (m->nRowBlocks + 7) / 8;
     hipLaunchKernelGGL(spmv_crs_stream, dim3(per * 8), dim3(CRS_THREADS), 0, g.stream, m->rowBlocks,
         m->rowPtr, m->colInd, m->val, x, y, m->nRowBlocks, per, stop);
@@ -673,118 +677,57 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
       g_scs_nt      = n ? atoi(n) : 1;
       const char* xc = getenv("SB_SCS_XCD");
       g_scs_xcd     = xc ? atoi(xc) : 1;
-      const char* pp = getenv("SB_SCS_PIPE");
-      g_scs_pipe    = pp ? atoi(pp) : 0;
     }
     const uint32_t nBlocks = (m->nChunks + 3) / 4;
     const uint32_t per     = g_scs_xcd ? (nBlocks + 7) / 8 : 0;
     dim3 grid(g_scs_xcd ? per * 8 : nBlocks), block(256);
     if (m->usePacked == 2) {
       const size_t shmem = (256 + (size_t)m->ldsWindow) * sizeof(double);
-#define LDS_LAUNCH(DI, DO)                                                                              \
+#define LDS_LAUNCH(DI, DO)                                                                                   \
   hipLaunchKernelGGL((spmv_scs64_lds<DI, DO>), grid, block, shmem, g.stream, m->pmeta, m->pslots, m->pcodes, \
       m->pdict, m->chunkPtr, m->val, m->tileSegPtr, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol,    \
       dotPartials, stop)
       if (m->nDict > 0) {
-        if (dotPartials) LDS_LAUNCH(true, true);
+        if (dot) LDS_LAUNCH(true, true);
         else LDS_LAUNCH(true, false);
       } else {
-        if (dotPartials) LDS_LAUNCH(false, true);
+        if (dot) LDS_LAUNCH(false, true);
         else LDS_LAUNCH(false, false);
       }
 #undef LDS_LAUNCH
-      HIP_CHECK(hipGetLastError());
-      return;
-    }
-    if (m->usePacked) {
-#define PK_LAUNCH(DI, DO)                                                                              \
+    } else if (m->usePacked == 1) {
+#define PK_LAUNCH(DI, DO)                                                                                 \
   hipLaunchKernelGGL((spmv_scs64_packed<DI, DO>), grid, block, 0, g.stream, m->pmeta, m->pidx, m->pcodes, \
       m->pdict, m->chunkPtr, m->val, x, y, m->nr, m->nChunks, per, m->padCol, dotPartials, stop)
-#define PKB_LAUNCH(DI, DO, GBN)                                                                        \
-  hipLaunchKernelGGL((spmv_scs64_packed_b<DI, DO, GBN>), grid, block, 0, g.stream, m->pmeta, m->pidx,  \
-      m->pcodes, m->pdict, m->chunkPtr, m->val, x, y, m->nr, m->nChunks, per, m->padCol, dotPartials, stop)
-#define PKB_PICK(GBN)                                                              \
-  do {                                                                             \
-    if (m->nDict > 0) { if (dotPartials) PKB_LAUNCH(true, true, GBN); else PKB_LAUNCH(true, false, GBN); }   \
-    else { if (dotPartials) PKB_LAUNCH(false, true, GBN); else PKB_LAUNCH(false, false, GBN); }                   \
-  } while (0)
-      static int gb = -1;
-      if (gb < 0) {
-        const char* e = getenv("SB_PACK_GB");
-        gb            = e ? atoi(e) : 0; // 0: simple loop (fastest measured, full occupancy)
+      if (m->nDict > 0) {
+        if (dot) PK_LAUNCH(true, true);
+        else PK_LAUNCH(true, false);
+      } else {
+        if (dot) PK_LAUNCH(false, true);
+        else PK_LAUNCH(false, false);
       }
-#define PKC_LAUNCH(DI, DO, SGN)                                                                        \
-  hipLaunchKernelGGL((spmv_scs64_packed_c<DI, DO, SGN>), grid, block, 0, g.stream, m->pmeta, m->pidx,  \
-      m->pcodes, m->pdict, m->chunkPtr, m->val, x, y, m->nr, m->nChunks, per, m->padCol, dotPartials, stop)
-#define PKC_PICK(SGN)                                                              \
-  do {                                                                             \
-    if (m->nDict > 0) { if (dotPartials) PKC_LAUNCH(true, true, SGN); else PKC_LAUNCH(true, false, SGN); }   \
-    else { if (dotPartials) PKC_LAUNCH(false, true, SGN); else PKC_LAUNCH(false, false, SGN); }                   \
-  } while (0)
-      switch (gb) {
-      case 104: PKC_PICK(4); break;
-      case 108: PKC_PICK(8); break;
-      case 2: PKB_PICK(2); break;
-      case 4: PKB_PICK(4); break;
-      case 7: PKB_PICK(7); break;
-      case 8: PKB_PICK(8); break;
-      default:
-        if (m->nDict > 0) {
-          if (dotPartials) PK_LAUNCH(true, true);
-          else PK_LAUNCH(true, false);
-        } else {
-          if (dotPartials) PK_LAUNCH(false, true);
-          else PK_LAUNCH(false, false);
-        }
-      }
-#undef PKB_PICK
-#undef PKB_LAUNCH
 #undef PK_LAUNCH
-      HIP_CHECK(hipGetLastError());
-      return;
-    }
+    } else {
 #define SCS_LAUNCH(U, D, N)                                                                      \
   hipLaunchKernelGGL((spmv_scs64<U, D, N>), grid, block, 0, g.stream, m->chunkPtr, m->chunkLens, \
       m->colInd, m->val, x, y, m->nr, m->nChunks, per, dotPartials, stop)
-#define SCS_PICK(U)                                                  \
-  do {                                                               \
-    if (dotPartials) { if (g_scs_nt) SCS_LAUNCH(U, true, true); else SCS_LAUNCH(U, true, false); }   \
-    else { if (g_scs_nt) SCS_LAUNCH(U, false, true); else SCS_LAUNCH(U, false, false); }             \
+#define SCS_PICK(U)                                                                           \
+  do {                                                                                        \
+    if (dot) { if (g_scs_nt) SCS_LAUNCH(U, true, true); else SCS_LAUNCH(U, true, false); }    \
+    else { if (g_scs_nt) SCS_LAUNCH(U, false, true); else SCS_LAUNCH(U, false, false); }      \
   } while (0)
-#define PIPE_LAUNCH(U, D)                                                                        \
-  hipLaunchKernelGGL((spmv_scs64_pipe<U, D>), grid, block, 0, g.stream, m->chunkPtr, m->chunkLens, \
-      m->colInd, m->val, x, y, m->nr, m->nChunks, per, dotPartials, stop)
-#define PIPE_PICK(U)                                        \
-  do {                                                      \
-    if (dotPartials) PIPE_LAUNCH(U, true);                  \
-    else PIPE_LAUNCH(U, false);                             \
-  } while (0)
-    if (g_scs_pipe) {
       switch (g_scs_unroll) {
-      case 2: PIPE_PICK(2); break;
-      case 3: PIPE_PICK(3); break;
-      case 5: PIPE_PICK(5); break;
-      case 7: PIPE_PICK(7); break;
-      case 8: PIPE_PICK(8); break;
-      case 9: PIPE_PICK(9); break;
-      case 14: PIPE_PICK(14); break;
-      default: PIPE_PICK(4); break;
+      case 1: SCS_PICK(1); break;
+      case 2: SCS_PICK(2); break;
+      case 8: SCS_PICK(8); break;
+      case 9: SCS_PICK(9); break;
+      default: SCS_PICK(4); break;
       }
-    } else
-    switch (g_scs_unroll) {
-    case 1: SCS_PICK(1); break;
-    case 2: SCS_PICK(2); break;
-    case 8: SCS_PICK(8); break;
-    case 9: SCS_PICK(9); break;
-    case 14: SCS_PICK(14); break;
-    default: SCS_PICK(4); break;
-    }
-#undef PIPE_PICK
-#undef PIPE_LAUNCH
 #undef SCS_PICK
 #undef SCS_LAUNCH
+    }
   } else {
-    if (dotPartials) SB_FATAL("fused dot is an SCS C=64 feature");
+    if (dot) SB_FATAL("fused dot is an SCS C=64 feature");
     hipLaunchKernelGGL(spmv_scs_generic, dim3((m->nrPadded + 255) / 256), dim3(256), 0, g.stream,
         m->chunkPtr, m->chunkLens, m->colInd, m->val, x, y, m->nr, m->nrPadded, m->C, stop);
   }
@@ -853,21 +796,25 @@ void sb_waxpby(uint32_t n, double alpha, const double* x, double beta, const dou
   launch_waxpby(n, alpha, x, beta, y, w, nullptr);
 }
 
-static void launch_dot_partials(uint32_t n, const double* x, const double* y, double* partials,
-    const int* stop)
+// OP 0 dot(a,b) / OP 1 x,r update + r.r / OP 2 r = b - Ap + r.r  (kernels.hip.h: dot_spans_k);
+// partials receives 4*ceil(n/256) level-0 partials (tail zeroed)
+static void launch_dot_spans(int op, uint32_t n, const double* a, const double* b, double* x, double* r,
+    const CgScalars* S, double* partials, const int* stop)
 {
   if (n == 0) return;
-  if (((uintptr_t)x | (uintptr_t)y) & 15u) SB_FATAL("ddot: vectors must be 16-byte aligned");
-  const uint32_t nSpans = (n + 127) / 128;
-  hipLaunchKernelGGL(ddot_partials_k, dim3(stream_grid(nSpans, 4)), dim3(256), 0, g.stream, n, x, y,
-      partials, stop);
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)x | (uintptr_t)r) & 15u) SB_FATAL("vectors must be 16-byte aligned");
+  const uint32_t nSpans = ((n + 255u) / 256u) * 2u;
+  const dim3 grid(stream_grid(nSpans, 4)), block(256);
+  if (op == 0) hipLaunchKernelGGL((dot_spans_k<0>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
+  else if (op == 1) hipLaunchKernelGGL((dot_spans_k<1>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
+  else hipLaunchKernelGGL((dot_spans_k<2>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
   HIP_CHECK(hipGetLastError());
 }
 
 void sb_ddot_partials(uint32_t n, const double* x, const double* y, double* partials_dev)
 {
   need_init();
-  launch_dot_partials(n, x, y, partials_dev, nullptr);
+  launch_dot_spans(0, n, x, y, nullptr, nullptr, nullptr, partials_dev, nullptr);
 }
 
 void sb_reduce_final(uint32_t m, const double* partials_dev, double* result_dev)
@@ -881,9 +828,9 @@ void sb_reduce_final(uint32_t m, const double* partials_dev, double* result_dev)
 void sb_ddot_async(uint32_t n, const double* x, const double* y, double* result_dev)
 {
   need_init();
-  const uint32_t m = (n + 63) / 64;
-  double* q        = scratch_partials(m);
-  launch_dot_partials(n, x, y, q, nullptr);
+  const uint32_t m = (n + 255u) / 256u;
+  double* q        = scratch_partials(4 * (size_t)m);
+  sb_ddot_partials(n, x, y, q);
   sb_reduce_final(m, q, result_dev);
   if (g.comm) sb_comm_reduction(result_dev, 1);
 }
@@ -1126,8 +1073,10 @@ sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host, con
     HIP_CHECK(hipStreamSynchronize(g.stream));
   }
   s->S         = (CgScalars*)sb_malloc(sizeof(CgScalars));
-  s->nPartials = (m->nr + 63) / 64;
-  s->partials  = (double*)sb_malloc(((size_t)s->nPartials + 2) * sizeof(double));
+  s->nPartials = (m->nr + 255) / 256;
+  // level-0 partials: 4 per 256 rows; the tail beyond the last chunk stays +0.0
+  s->partials = (double*)sb_malloc((4 * (size_t)s->nPartials + 4) * sizeof(double));
+  HIP_CHECK(hipMemsetAsync(s->partials, 0, (4 * (size_t)s->nPartials + 4) * sizeof(double), g.stream));
   s->hist_cap  = 0;
   s->rr_hist = s->pAp_hist = nullptr;
   s->fused      = 1;
@@ -1139,6 +1088,8 @@ sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host, con
   s->loop_ms    = 0.f;
   s->spmvTiming = false;
   s->spmvEvUsed = 0;
+  s->k_next     = 1;
+  s->started    = false;
   HIP_CHECK(hipEventCreate(&s->evLoop0));
   HIP_CHECK(hipEventCreate(&s->evLoop1));
   for (double& v : s->region_ms) v = 0.0;
@@ -1159,12 +1110,15 @@ void sb_cg_free(sb_cg* s)
   delete s;
 }
 
+static void drop_graph(sb_cg* s)
+{
+  if (s->iterGraph) HIP_CHECK(hipGraphExecDestroy(s->iterGraph));
+  s->iterGraph = nullptr, s->graphReady = false;
+}
+
 void sb_cg_set_fused(sb_cg* s, int fused)
 {
-  if (s->fused != fused && s->iterGraph) {
-    HIP_CHECK(hipGraphExecDestroy(s->iterGraph));
-    s->iterGraph = nullptr, s->graphReady = false;
-  }
+  if (s->fused != fused) drop_graph(s);
   s->fused = fused;
 }
 void sb_cg_set_graph(sb_cg* s, int use_graph) { s->use_graph = use_graph; }
@@ -1198,25 +1152,24 @@ void sb_cg_counters(const sb_cg* s, int out[5])
   out[0] = h.stop, out[1] = h.stop_next, out[2] = h.iters, out[3] = h.n_rr, out[4] = h.n_pAp;
 }
 
-static bool can_fuse_dot(const sb_cg* s) { return s->fused && s->A->fmt == 1 && s->A->C == 64; }
+static bool spmv_can_fuse_dot(const sb_cg* s) { return s->fused && s->A->fmt == 1 && s->A->C == 64; }
 
-// r.r / p.Ap epilogue: partials -> (all-reduce) -> scalar update, all on device
-template <int MODE> static void scalar_step(sb_cg* s, double eps)
+// levels 1-2 of the reduction + the scalar step: one 1-workgroup launch after the producer
+// (several ranks: local sum -> RCCL all-reduce in place on the stream -> scalar step;
+// MPI_Allreduce of src/comm.c:659)
+template <int MODE> static void scalar_launch(sb_cg* s)
 {
-  const bool multi = g.comm != nullptr;
-  if (!multi) {
-    hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials,
-        s->partials, s->S, eps, s->rr_hist, s->pAp_hist, s->hist_cap, 0);
-  } else {
-    hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials,
-        s->partials, s->S, eps, s->rr_hist, s->pAp_hist, s->hist_cap, 1);
+  hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
+      s->S, s->rr_hist, s->pAp_hist, g.comm ? 1 : 0);
+  HIP_CHECK(hipGetLastError());
+  if (g.comm) {
     mark(s, R_DDOT);
     sb_comm_reduction(&s->S->local, 1);
     mark(s, R_COMM);
-    hipLaunchKernelGGL((cg_scalar_k<MODE, false>), dim3(1), dim3(1024), 0, g.stream, s->nPartials,
-        s->partials, s->S, eps, s->rr_hist, s->pAp_hist, s->hist_cap, 0);
+    hipLaunchKernelGGL((cg_scalar_k<MODE, false>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
+        s->S, s->rr_hist, s->pAp_hist, 0);
+    HIP_CHECK(hipGetLastError());
   }
-  HIP_CHECK(hipGetLastError());
 }
 
 static void spmv_event(sb_cg* s)
@@ -1230,13 +1183,32 @@ static void spmv_event(sb_cg* s)
   HIP_CHECK(hipEventRecord(s->spmvEv[s->spmvEvUsed++], g.stream));
 }
 
-static void spmv_and_dot(sb_cg* s, double eps)
-{ // COMM: halo ; SPMVM: Ap = A p ; DDOT: p.Ap -> alpha   (src/CGSolver.c:122-126)
-  const int* stop = &s->S->stop;
-  halo_exchange(s->halo, s->p, stop);
+// one loop body of solveCG (src/CGSolver.c:108-128).  Fused path: the r.r partials of the
+// NEXT body come out of this body's x/r update, and its beta + loop test are taken right
+// after it, so a body is: p update | SpMV (+p.Ap partials) | alpha | x/r update (+r.r
+// partials) | beta, loop test.
+static void loop_body(sb_cg* s, int k)
+{
+  const uint32_t n = s->nr;
+  const int* stop  = &s->S->stop;
+  dim3 gridV(stream_grid(n / 2 + 1, 256)), blockV(256);
+  if (k == 1) {
+    if (n) hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, s->S, 1); // p = r (:109)
+    mark(s, R_WAXPBY);
+  } else {
+    if (!s->fused) { // rtrans = r.r ; beta (:111-113)
+      launch_dot_spans(0, n, s->r, s->r, nullptr, nullptr, s->S, s->partials, stop);
+      scalar_launch<1>(s);
+      mark(s, R_DDOT);
+    }
+    if (n) hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, s->S, 0); // :114
+    mark(s, R_WAXPBY);
+  }
+  HIP_CHECK(hipGetLastError());
+  halo_exchange(s->halo, s->p, stop); // :122
   mark(s, R_COMM);
   spmv_event(s);
-  if (can_fuse_dot(s)) {
+  if (spmv_can_fuse_dot(s)) { // Ap = A p, alpha = rtrans / p.Ap (:123-126)
     launch_spmv(s->A, s->p, s->Ap, s->partials, stop);
     spmv_event(s);
     mark(s, R_SPMVM);
@@ -1244,51 +1216,21 @@ static void spmv_and_dot(sb_cg* s, double eps)
     launch_spmv(s->A, s->p, s->Ap, nullptr, stop);
     spmv_event(s);
     mark(s, R_SPMVM);
-    launch_dot_partials(s->nr, s->p, s->Ap, s->partials, stop);
+    launch_dot_spans(0, n, s->p, s->Ap, nullptr, nullptr, s->S, s->partials, stop);
   }
-  scalar_step<2>(s, eps);
+  scalar_launch<2>(s);
   mark(s, R_DDOT);
-}
-
-static void update_x_r(sb_cg* s)
-{ // x += alpha p ; r -= alpha Ap (+ partials of the next r.r)   (:127-128, :112)
-  const uint32_t n = s->nr;
-  if (s->fused) {
-    hipLaunchKernelGGL(cg_update_xr_dot, dim3(stream_grid((n + 127) / 128, 4)), dim3(256), 0, g.stream, n,
-        s->x, s->p, s->r, s->Ap, s->S, s->partials);
-    HIP_CHECK(hipGetLastError());
+  if (s->fused) { // x += alpha p ; r -= alpha Ap (:127-128) + next r.r, beta, loop test
+    launch_dot_spans(1, n, s->p, s->Ap, s->x, s->r, s->S, s->partials, stop);
     mark(s, R_WAXPBY);
-  } else {
-    // the reference's two waxpby calls; alpha / -alpha come from the control block
-    dim3 gridV(stream_grid(n / 2 + 1, 256)), blockV(256);
-    hipLaunchKernelGGL(waxpby_sdev_k, gridV, blockV, 0, g.stream, n, s->x, &s->S->alpha, s->p, s->x,
-        &s->S->stop);
-    hipLaunchKernelGGL(waxpby_sdev_k, gridV, blockV, 0, g.stream, n, s->r, &s->S->neg_alpha, s->Ap,
-        s->r, &s->S->stop);
-    HIP_CHECK(hipGetLastError());
-    mark(s, R_WAXPBY);
-  }
-}
-
-static void loop_body(sb_cg* s, int k, double eps)
-{
-  const uint32_t n = s->nr;
-  dim3 gridV(stream_grid(n / 2 + 1, 256)), blockV(256);
-  if (k == 1) {
-    hipLaunchKernelGGL(cg_iter1_begin, dim3(1), dim3(1), 0, g.stream, s->S);
-    hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, s->S, 1);
-    HIP_CHECK(hipGetLastError());
-    mark(s, R_WAXPBY);
-  } else {
-    if (!s->fused) launch_dot_partials(n, s->r, s->r, s->partials, &s->S->stop);
-    scalar_step<1>(s, eps);
+    scalar_launch<1>(s);
     mark(s, R_DDOT);
-    hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, s->S, 0);
+  } else if (n) {
+    hipLaunchKernelGGL(waxpby_sdev_k, gridV, blockV, 0, g.stream, n, s->x, &s->S->alpha, s->p, s->x, stop);
+    hipLaunchKernelGGL(waxpby_sdev_k, gridV, blockV, 0, g.stream, n, s->r, &s->S->neg_alpha, s->Ap, s->r, stop);
     HIP_CHECK(hipGetLastError());
     mark(s, R_WAXPBY);
   }
-  spmv_and_dot(s, eps);
-  update_x_r(s);
 }
 
 static void ensure_hist(sb_cg* s, int cap)
@@ -1298,22 +1240,19 @@ static void ensure_hist(sb_cg* s, int cap)
   s->hist_cap = cap;
   s->rr_hist  = (double*)sb_malloc((size_t)cap * sizeof(double));
   s->pAp_hist = (double*)sb_malloc((size_t)cap * sizeof(double));
-  if (s->iterGraph) { // captured pointers are stale
-    HIP_CHECK(hipGraphExecDestroy(s->iterGraph));
-    s->iterGraph = nullptr, s->graphReady = false;
-  }
+  drop_graph(s); // captured pointers are stale
 }
 
-static void run_body_maybe_graph(sb_cg* s, double eps)
+static void run_body_maybe_graph(sb_cg* s, int k)
 { // k >= 2 bodies are iteration-invariant (k lives in the device control block)
-  if (!s->use_graph || g.comm || s->timing || s->spmvTiming) {
-    loop_body(s, 2, eps);
+  if (k < 2 || !s->use_graph || g.comm || s->timing || s->spmvTiming) {
+    loop_body(s, k);
     return;
   }
   if (!s->graphReady) {
     hipGraph_t graph;
     HIP_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
-    loop_body(s, 2, eps);
+    loop_body(s, 2);
     HIP_CHECK(hipStreamEndCapture(g.stream, &graph));
     HIP_CHECK(hipGraphInstantiate(&s->iterGraph, graph, nullptr, nullptr, 0));
     HIP_CHECK(hipGraphDestroy(graph));
@@ -1322,18 +1261,19 @@ static void run_body_maybe_graph(sb_cg* s, double eps)
   HIP_CHECK(hipGraphLaunch(s->iterGraph, g.stream));
 }
 
-static double g_last_eps = 0.0;
-
-int sb_cg_solve(sb_cg* s, int itermax, double eps)
+void sb_cg_start(sb_cg* s, int itermax, double eps)
 {
   need_init();
   const uint32_t n = s->nr;
   ensure_hist(s, itermax + 2);
-  g_last_eps = eps;
   s->timing  = !s->fused; // the reference-shaped op list is the one that gets the region table
   s->evUsed  = 0;
-  HIP_CHECK(hipMemsetAsync(s->S, 0, sizeof(CgScalars), g.stream));
-  HIP_CHECK(hipMemsetAsync(s->x, 0, (size_t)n * sizeof(double), g.stream));   // x0 = 0 (:28)
+  memset(&s->hostS, 0, sizeof s->hostS);
+  s->hostS.itermax  = itermax;
+  s->hostS.eps      = eps;
+  s->hostS.hist_cap = s->hist_cap;
+  HIP_CHECK(hipMemcpyAsync(s->S, &s->hostS, sizeof(CgScalars), hipMemcpyHostToDevice, g.stream));
+  HIP_CHECK(hipMemsetAsync(s->x, 0, (size_t)n * sizeof(double), g.stream)); // x0 = 0 (:28)
   HIP_CHECK(hipMemsetAsync(s->p, 0, (size_t)s->nc * sizeof(double), g.stream));
   mark(s, -1);
   // prologue, src/CGSolver.c:94-100
@@ -1343,26 +1283,31 @@ int sb_cg_solve(sb_cg* s, int itermax, double eps)
   mark(s, R_COMM);
   launch_spmv(s->A, s->p, s->Ap, nullptr, nullptr);
   mark(s, R_SPMVM);
-  if (n && s->fused) {
-    hipLaunchKernelGGL(cg_residual_dot, dim3(stream_grid((n + 127) / 128, 4)), dim3(256), 0, g.stream, n,
-        s->b, s->Ap, s->r, s->partials);
-    HIP_CHECK(hipGetLastError());
+  if (s->fused) {
+    launch_dot_spans(2, n, s->b, s->Ap, nullptr, s->r, s->S, s->partials, nullptr);
     mark(s, R_WAXPBY);
-  } else if (n) {
+  } else {
     launch_waxpby(n, 1.0, s->b, -1.0, s->Ap, s->r, nullptr);
     mark(s, R_WAXPBY);
-    launch_dot_partials(n, s->r, s->r, s->partials, nullptr);
+    launch_dot_spans(0, n, s->r, s->r, nullptr, nullptr, s->S, s->partials, nullptr);
   }
-  scalar_step<0>(s, eps);
+  scalar_launch<0>(s);
   mark(s, R_DDOT);
-  HIP_CHECK(hipEventRecord(s->evLoop0, g.stream));
-  for (int k = 1; k < itermax; k++) {
-    if (k == 1) loop_body(s, 1, eps);
-    else run_body_maybe_graph(s, eps);
-  }
-  HIP_CHECK(hipEventRecord(s->evLoop1, g.stream));
+  s->k_next  = 1;
+  s->started = true;
+}
+
+void sb_cg_run_iters(sb_cg* s, int iters)
+{
+  need_init();
+  if (!s->started) SB_FATAL("sb_cg_run_iters before sb_cg_start");
+  for (int i = 0; i < iters; i++) run_body_maybe_graph(s, s->k_next++);
+}
+
+int sb_cg_finish(sb_cg* s)
+{
+  need_init();
   HIP_CHECK(hipStreamSynchronize(g.stream));
-  HIP_CHECK(hipEventElapsedTime(&s->loop_ms, s->evLoop0, s->evLoop1));
   CgScalars h;
   HIP_CHECK(hipMemcpy(&h, s->S, sizeof h, hipMemcpyDeviceToHost));
   if (s->timing) {
@@ -1377,10 +1322,15 @@ int sb_cg_solve(sb_cg* s, int itermax, double eps)
   return h.iters + 1; // the value of k when the reference's for loop exits (:107,:140)
 }
 
-void sb_cg_run_iters(sb_cg* s, int iters)
+int sb_cg_solve(sb_cg* s, int itermax, double eps)
 {
-  need_init();
-  for (int i = 0; i < iters; i++) run_body_maybe_graph(s, g_last_eps);
+  sb_cg_start(s, itermax, eps);
+  HIP_CHECK(hipEventRecord(s->evLoop0, g.stream));
+  sb_cg_run_iters(s, itermax > 1 ? itermax - 1 : 0);
+  HIP_CHECK(hipEventRecord(s->evLoop1, g.stream));
+  const int k = sb_cg_finish(s);
+  HIP_CHECK(hipEventElapsedTime(&s->loop_ms, s->evLoop0, s->evLoop1));
+  return k;
 }
 
 int sb_cg_history(const sb_cg* s, double* rr_out, int rr_cap, double* pAp_out, int pAp_cap, int* n_pAp)
@@ -1458,4 +1408,3 @@ void sb_cg_region_ms(const sb_cg* s, double out[4])
 {
   for (int i = 0; i < 4; i++) out[i] = s->region_ms[i];
 }
-

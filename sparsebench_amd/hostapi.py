@@ -170,8 +170,16 @@ class CG:
         self.itermax = itermax
         return self.L.sb_cg_solve(self.ptr, itermax, eps)
 
+    def start(self, itermax, eps=0.0):
+        """prologue only; follow with run_iters() and finish()"""
+        self.itermax = itermax
+        self.L.sb_cg_start(self.ptr, itermax, eps)
+
     def run_iters(self, iters):
         self.L.sb_cg_run_iters(self.ptr, iters)
+
+    def finish(self):
+        return self.L.sb_cg_finish(self.ptr)
 
     def history(self):
         cap = self.itermax + 2

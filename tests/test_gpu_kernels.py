@@ -199,11 +199,18 @@ def test_waxpby_and_ddot_bit_exact(gpu, n):
     x2 = po.waxpby(1.0, x, -2.0, y2)
     assert np.array_equal(dx.get(), x2)
     # fixed-order dot, both stages
-    m = (n + 63) // 64
-    dq = DeviceVector(max(m, 1))
+    m = (n + 255) // 256
+    dq = DeviceVector.from_host(np.full(max(4 * m, 1), 9.9))  # level 0: 4 partials per 256 elements
     L.sb_ddot_partials(n, dx.ptr, dy.ptr, dq.ptr)
     if m:
-        assert np.array_equal(dq.get()[:m], po.ddot_partials(x2, y2))
+        q = dq.get()[:4 * m].reshape(m, 4)
+        assert np.all(q.reshape(-1)[(n + 63) // 64:] == 0.0)  # tail zeroed
+        lvl1 = ((q[:, 0] + q[:, 1]) + q[:, 2]) + q[:, 3]      # level 1, same IEEE adds
+        assert np.array_equal(lvl1, po.ddot_partials(x2, y2))
+        dres = DeviceVector(1)
+        L.sb_reduce_final(m, dq.ptr, dres.ptr)
+        assert dres.get()[0] == po.ddot_tree(x2, y2)
+        dres.free()
     assert L.sb_ddot(n, dx.ptr, dy.ptr) == po.ddot_tree(x2, y2)
     assert L.sb_ddot(n, dx.ptr, dx.ptr) == po.ddot_tree(x2, x2)
     if n:
