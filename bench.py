@@ -201,8 +201,10 @@ def main():
             barrier()
             t0 = time.perf_counter()
             cg.run_iters(seg)
-            barrier()
+            L.sb_sync()  # this rank's K steps are complete on its GPU ...
             dt = time.perf_counter() - t0
+            barrier()    # ... and nobody moves on before all are (the max over ranks is taken below;
+            #                 the gloo TCP barrier itself is control plane, not part of a CG step)
             after = cg.counters()
             cg.finish()
             if after["stop"] and after["iters"] != W + 1 + seg:
