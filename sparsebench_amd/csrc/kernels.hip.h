@@ -37,7 +37,7 @@ struct CgScalars {
   int n_pAp;
   int itermax;
   int hist_cap;
-  int pad;
+  int x_pending;  // 1: x += alpha p of the last body is still owed (applied by the next p update)
 };
 
 // ---- wave-level fixed-order reductions --------------------------------------
@@ -118,7 +118,7 @@ __device__ __forceinline__ double reduce_final_1024(uint32_t m, const double* __
 // the r.r / beta of that iteration (:111-113,:116).  MODE 2: p.Ap -> alpha (:124-126).
 template <int MODE>
 __device__ __forceinline__ void cg_apply(CgScalars* S, double total, double* rr_hist,
-    double* pAp_hist)
+    double* pAp_hist, int defer_x)
 {
   if (MODE == 0) {
     const int sn = !(sqrt(total) > S->eps);
@@ -141,7 +141,9 @@ __device__ __forceinline__ void cg_apply(CgScalars* S, double total, double* rr_
     } else {
       S->stop = 1;
     }
+    if (defer_x) S->x_pending = 1; // the body that just ran left "x += alpha p" to the next p update
   } else {
+    S->x_pending    = 0; // consumed by the p update that preceded this SpMV
     S->pAp          = total;
     const double al = S->rr / total;
     S->alpha        = al;
@@ -368,25 +370,48 @@ __global__ __launch_bounds__(256) void waxpby_sdev_k(uint32_t n, const double* x
 // same, scalars read from the device-resident control block (no host round trip):
 // which = 0: p = r + beta*p            (src/CGSolver.c:114)
 // which = 1: p = r + 0.0*r             (:109, the literal k==1 form)
+// If x != NULL and the previous body left its "x = x + alpha p" (:127) pending, it is
+// applied here, where the old p is in registers anyway (saves one read of p per
+// iteration); the arithmetic and its order per element are unchanged.
 __global__ __launch_bounds__(256) void cg_update_p(uint32_t n, const double* __restrict__ r,
-    double* p, const CgScalars* __restrict__ S, int which)
+    double* p, double* x, const CgScalars* __restrict__ S, int which)
 {
   if (S->stop) return;
   const double beta     = which == 0 ? S->beta : 0.0;
+  const bool owed       = x != nullptr && which == 0 && S->x_pending;
+  const double alpha    = S->alpha;
   const uint32_t n2     = n >> 1;
   const uint32_t stride = gridDim.x * blockDim.x;
   const double2* r2     = reinterpret_cast<const double2*>(r);
   double2* p2           = reinterpret_cast<double2*>(p);
+  double2* x2           = reinterpret_cast<double2*>(x);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
     double2 a = r2[i], b = which == 0 ? p2[i] : a, o;
+    if (owed) {
+      double2 xv = x2[i];
+      xv.x = xv.x + alpha * b.x;
+      xv.y = xv.y + alpha * b.y;
+      x2[i] = xv;
+    }
     o.x = a.x + beta * b.x;
     o.y = a.y + beta * b.y;
     p2[i] = o;
   }
   if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) {
     const double b = which == 0 ? p[n - 1] : r[n - 1];
-    p[n - 1]       = r[n - 1] + beta * b;
+    if (owed) x[n - 1] = x[n - 1] + alpha * b;
+    p[n - 1] = r[n - 1] + beta * b;
   }
+}
+
+// the owed "x = x + alpha p" of the LAST body that ran (nobody comes after it)
+__global__ __launch_bounds__(256) void cg_x_finalize(uint32_t n, double* x, const double* __restrict__ p,
+    const CgScalars* __restrict__ S)
+{
+  if (!S->x_pending) return;
+  const double alpha    = S->alpha;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = x[i] + alpha * p[i];
 }
 
 // ---- dot-producing vector kernels -------------------------------------------------------
@@ -397,6 +422,7 @@ __global__ __launch_bounds__(256) void cg_update_p(uint32_t n, const double* __r
 // OP 0: dot(a, b)                                       (ddot, src/solver.c:41-62)
 // OP 1: x += alpha p ; r -= alpha Ap ; dot(r, r)        (src/CGSolver.c:127-128 + :112)
 // OP 2: r = b - Ap ; dot(r, r)                          (src/CGSolver.c:97-98)
+// OP 3: r -= alpha Ap ; dot(r, r)                       (x is updated by the next cg_update_p)
 template <int OP>
 __global__ __launch_bounds__(256) void dot_spans_k(uint32_t n, const double* a, const double* b,
     double* x, double* r, const CgScalars* __restrict__ S, double* __restrict__ partials,
@@ -407,7 +433,7 @@ __global__ __launch_bounds__(256) void dot_spans_k(uint32_t n, const double* a, 
   const uint32_t nSpans = ((n + 255u) >> 8) * 2u; // whole 256-groups
   const uint32_t nWaves = gridDim.x * (blockDim.x >> 6);
   double alpha = 0.0, nalpha = 0.0;
-  if (OP == 1) alpha = S->alpha, nalpha = -alpha;
+  if (OP == 1 || OP == 3) alpha = S->alpha, nalpha = -alpha;
   for (uint32_t s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < nSpans; s += nWaves) {
     const uint32_t e = s * 128u + lane * 2u;
     double t         = 0.0;
@@ -434,6 +460,19 @@ __global__ __launch_bounds__(256) void dot_spans_k(uint32_t n, const double* a, 
         t = rv.x * rv.x + rv.y * rv.y;
       } else if (e < n) {
         x[e]            = x[e] + alpha * a[e];
+        const double rn = r[e] + nalpha * b[e];
+        r[e]            = rn;
+        t               = rn * rn + 0.0;
+      }
+    } else if (OP == 3) { // b = Ap
+      if (e + 1 < n) {
+        double2 rv       = *reinterpret_cast<double2*>(r + e);
+        const double2 av = *reinterpret_cast<const double2*>(b + e);
+        rv.x = rv.x + nalpha * av.x;
+        rv.y = rv.y + nalpha * av.y;
+        *reinterpret_cast<double2*>(r + e) = rv;
+        t = rv.x * rv.x + rv.y * rv.y;
+      } else if (e < n) {
         const double rn = r[e] + nalpha * b[e];
         r[e]            = rn;
         t               = rn * rn + 0.0;
@@ -472,22 +511,27 @@ __global__ __launch_bounds__(1024) void reduce_final_k(uint32_t m, const double*
 // all-reduce on several ranks (REDUCE = false: the sum is already in S->local).
 template <int MODE, bool REDUCE>
 __global__ __launch_bounds__(1024) void cg_scalar_k(uint32_t m, const double* __restrict__ q,
-    CgScalars* S, double* __restrict__ rr_hist, double* __restrict__ pAp_hist, int to_local)
+    CgScalars* S, double* __restrict__ rr_hist, double* __restrict__ pAp_hist, int to_local, int defer_x)
 {
   __shared__ double lds16[16];
-  if (S->stop) return;
+  // This launch sits on the critical path of every iteration: do not serialise the flag's
+  // round trip in front of the partial loads -- read it, reduce (harmless if the loop has
+  // already exited), and only then branch on it.
+  const int stopped = S->stop;
   double total;
   if (REDUCE) {
     total = reduce_final_1024(m, q, lds16);
+    if (stopped) return;
     if (to_local) {
       if (threadIdx.x == 0) S->local = total;
       return;
     }
   } else {
     total = S->local;
+    if (stopped) return;
   }
   __syncthreads();
-  if (threadIdx.x == 0) cg_apply<MODE>(S, total, rr_hist, pAp_hist);
+  if (threadIdx.x == 0) cg_apply<MODE>(S, total, rr_hist, pAp_hist, defer_x);
 }
 
 // =============================================================================

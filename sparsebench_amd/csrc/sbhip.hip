@@ -807,7 +807,8 @@ static void launch_dot_spans(int op, uint32_t n, const double* a, const double* 
   const dim3 grid(stream_grid(nSpans, 4)), block(256);
   if (op == 0) hipLaunchKernelGGL((dot_spans_k<0>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
   else if (op == 1) hipLaunchKernelGGL((dot_spans_k<1>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
-  else hipLaunchKernelGGL((dot_spans_k<2>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
+  else if (op == 2) hipLaunchKernelGGL((dot_spans_k<2>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
+  else hipLaunchKernelGGL((dot_spans_k<3>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1157,17 +1158,17 @@ static bool spmv_can_fuse_dot(const sb_cg* s) { return s->fused && s->A->fmt == 
 // levels 1-2 of the reduction + the scalar step: one 1-workgroup launch after the producer
 // (several ranks: local sum -> RCCL all-reduce in place on the stream -> scalar step;
 // MPI_Allreduce of src/comm.c:659)
-template <int MODE> static void scalar_launch(sb_cg* s)
+template <int MODE> static void scalar_launch(sb_cg* s, int defer_x = 0)
 {
   hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
-      s->S, s->rr_hist, s->pAp_hist, g.comm ? 1 : 0);
+      s->S, s->rr_hist, s->pAp_hist, g.comm ? 1 : 0, defer_x);
   HIP_CHECK(hipGetLastError());
   if (g.comm) {
     mark(s, R_DDOT);
     sb_comm_reduction(&s->S->local, 1);
     mark(s, R_COMM);
     hipLaunchKernelGGL((cg_scalar_k<MODE, false>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
-        s->S, s->rr_hist, s->pAp_hist, 0);
+        s->S, s->rr_hist, s->pAp_hist, 0, defer_x);
     HIP_CHECK(hipGetLastError());
   }
 }
@@ -1193,7 +1194,7 @@ static void loop_body(sb_cg* s, int k)
   const int* stop  = &s->S->stop;
   dim3 gridV(stream_grid(n / 2 + 1, 256)), blockV(256);
   if (k == 1) {
-    if (n) hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, s->S, 1); // p = r (:109)
+    if (n) hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, (double*)nullptr, s->S, 1); // p = r (:109)
     mark(s, R_WAXPBY);
   } else {
     if (!s->fused) { // rtrans = r.r ; beta (:111-113)
@@ -1201,7 +1202,8 @@ static void loop_body(sb_cg* s, int k)
       scalar_launch<1>(s);
       mark(s, R_DDOT);
     }
-    if (n) hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, s->S, 0); // :114
+    if (n) // p = r + beta p (:114); fused path: also the x update owed by the previous body (:127)
+      hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, s->fused ? s->x : (double*)nullptr, s->S, 0);
     mark(s, R_WAXPBY);
   }
   HIP_CHECK(hipGetLastError());
@@ -1220,10 +1222,10 @@ static void loop_body(sb_cg* s, int k)
   }
   scalar_launch<2>(s);
   mark(s, R_DDOT);
-  if (s->fused) { // x += alpha p ; r -= alpha Ap (:127-128) + next r.r, beta, loop test
-    launch_dot_spans(1, n, s->p, s->Ap, s->x, s->r, s->S, s->partials, stop);
+  if (s->fused) { // r -= alpha Ap (:128) + next r.r, beta, loop test; x += alpha p (:127) is owed
+    launch_dot_spans(3, n, s->p, s->Ap, s->x, s->r, s->S, s->partials, stop);
     mark(s, R_WAXPBY);
-    scalar_launch<1>(s);
+    scalar_launch<1>(s, 1);
     mark(s, R_DDOT);
   } else if (n) {
     hipLaunchKernelGGL(waxpby_sdev_k, gridV, blockV, 0, g.stream, n, s->x, &s->S->alpha, s->p, s->x, stop);
@@ -1307,6 +1309,11 @@ void sb_cg_run_iters(sb_cg* s, int iters)
 int sb_cg_finish(sb_cg* s)
 {
   need_init();
+  if (s->nr) { // the x update the last body left to "the next p update": nobody comes after it
+    hipLaunchKernelGGL(cg_x_finalize, dim3(stream_grid(s->nr, 256)), dim3(256), 0, g.stream, s->nr, s->x, s->p, s->S);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemsetAsync(&s->S->x_pending, 0, sizeof(int), g.stream));
+  }
   HIP_CHECK(hipStreamSynchronize(g.stream));
   CgScalars h;
   HIP_CHECK(hipMemcpy(&h, s->S, sizeof h, hipMemcpyDeviceToHost));
