@@ -123,6 +123,21 @@ void sb_reduce_final(uint32_t m, const double* partials_dev, double* result_dev)
 #define SB_UNIQUE_ID_BYTES 128
 void sb_comm_unique_id(void* id_out);
 void sb_comm_init(int rank, int size, const void* id);
+/* Alternative to RCCL: a host-mediated transport supplied by the launcher (MPI without
+ * GPU awareness, gloo, ...).  Also what lets the N-rank device path be exercised by several
+ * processes sharing ONE GPU (tests/test_gpu_multirank.py).  Callbacks are entered with the
+ * layer's stream synchronised, get DEVICE pointers, and return when those are written. */
+typedef struct {
+  void* ctx;
+  /* commReduction: in place on one double; op 0 = MAX, 1 = SUM */
+  void (*allreduce)(void* ctx, double* v_dev, int op);
+  /* commExchange after packing: send_dev[sdispls[i] .. +sendCounts[i]) goes to destinations[i];
+   * recv_dev[rdispls[j] .. +recvCounts[j]) comes from sources[j] */
+  void (*neighbour_exchange)(void* ctx, const double* send_dev, int outdegree, const int* destinations,
+                             const int* sendCounts, const int* sdispls, double* recv_dev, int indegree,
+                             const int* sources, const int* recvCounts, const int* rdispls);
+} sb_transport;
+void sb_comm_init_transport(int rank, int size, const sb_transport* t);
 void sb_comm_finalize(void);
 int sb_comm_rank(void);
 int sb_comm_size(void);

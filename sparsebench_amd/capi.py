@@ -29,6 +29,7 @@ SYMBOLS = [
     "sb_cg_spmv_timing", "sb_cg_spmv_ms", "sb_cg_counters", "sb_debug_stream_read_gbs",
     "sb_matrix_pack_level", "sb_matrix_use_packed", "sb_matrix_stream_bytes",
     "sb_matrix_packed_mode", "sb_matrix_lds_window", "sb_cg_start", "sb_cg_finish",
+    "sb_comm_init_transport",
 ]
 
 _lib = None
@@ -118,6 +119,7 @@ def load():
         "sb_matrix_lds_window": (C.c_uint32, [vp]),
         "sb_cg_start": (None, [vp, C.c_int, C.c_double]),
         "sb_cg_finish": (C.c_int, [vp]),
+        "sb_comm_init_transport": (None, [C.c_int, C.c_int, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -125,6 +127,16 @@ def load():
         fn.argtypes = args
     _lib = L
     return L
+
+
+# include/sbhip.h: sb_transport
+ALLREDUCE_FN = C.CFUNCTYPE(None, vp, vp, C.c_int)
+EXCHANGE_FN = C.CFUNCTYPE(None, vp, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                          vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
+
+
+class TransportS(C.Structure):
+    _fields_ = [("ctx", vp), ("allreduce", ALLREDUCE_FN), ("neighbour_exchange", EXCHANGE_FN)]
 
 
 def init(device=None):

@@ -107,10 +107,14 @@ struct Ctx {
   double* scalar = nullptr; // one device double
   double* ws[2] = { nullptr, nullptr };
   size_t wsCap[2] = { 0, 0 };
-  // communicator
+  // communicator: RCCL, or a caller-provided host-mediated transport (sb_comm_init_transport)
   ncclComm_t comm = nullptr;
   int rank = 0, size = 1;
+  bool hasXport = false;
+  sb_transport xport;
 } g;
+
+inline bool multi_rank() { return g.comm != nullptr || g.hasXport; }
 
 void need_init()
 {
@@ -833,7 +837,7 @@ void sb_ddot_async(uint32_t n, const double* x, const double* y, double* result_
   double* q        = scratch_partials(4 * (size_t)m);
   sb_ddot_partials(n, x, y, q);
   sb_reduce_final(m, q, result_dev);
-  if (g.comm) sb_comm_reduction(result_dev, 1);
+  if (multi_rank()) sb_comm_reduction(result_dev, 1);
 }
 
 double sb_ddot(uint32_t n, const double* x, const double* y)
@@ -872,8 +876,18 @@ void sb_comm_init(int rank, int size, const void* idbytes)
   RCCL_CHECK(rccl.CommInitRank(&g.comm, size, id, rank));
 }
 
+void sb_comm_init_transport(int rank, int size, const sb_transport* t)
+{
+  need_init();
+  if (g.comm || g.hasXport) SB_FATAL("communicator already initialised");
+  if (size < 1 || rank < 0 || rank >= size || !t || !t->allreduce || !t->neighbour_exchange)
+    SB_FATAL("bad transport / rank %d / size %d", rank, size);
+  g.rank = rank, g.size = size, g.xport = *t, g.hasXport = true;
+}
+
 void sb_comm_finalize(void)
 {
+  g.hasXport = false;
   if (g.comm) {
     HIP_CHECK(hipStreamSynchronize(g.stream));
     RCCL_CHECK(rccl.CommDestroy(g.comm));
@@ -888,6 +902,11 @@ int sb_comm_size(void) { return g.size; }
 void sb_comm_reduction(double* v_dev, int op)
 {
   need_init();
+  if (g.hasXport) {
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    g.xport.allreduce(g.xport.ctx, v_dev, op);
+    return;
+  }
   if (!g.comm) return;
   RCCL_CHECK(rccl.AllReduce(v_dev, v_dev, 1, ncclFloat64_, op == 0 ? ncclMax_ : ncclSum_, g.comm,
       g.stream));
@@ -1015,6 +1034,13 @@ static void halo_exchange(sb_halo* h, double* x, const int* stop)
   // neighbour all-to-all (MPI_Neighbor_alltoallv, src/comm.c:640-648) as one
   // RCCL group of point-to-point transfers over xGMI, received straight into the
   // tail of x (no unpack), stream-ordered.
+  if (g.hasXport) {
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    g.xport.neighbour_exchange(g.xport.ctx, h->sendBuf, h->outdegree, h->destinations.data(),
+        h->sendCounts.data(), h->sdispls.data(), x + h->nr, h->indegree, h->sources.data(),
+        h->recvCounts.data(), h->rdispls.data());
+    return;
+  }
   RCCL_CHECK(rccl.GroupStart());
   for (int i = 0; i < h->outdegree; i++)
     RCCL_CHECK(rccl.Send(h->sendBuf + h->sdispls[i], (size_t)h->sendCounts[i], ncclFloat64_,
@@ -1161,9 +1187,9 @@ static bool spmv_can_fuse_dot(const sb_cg* s) { return s->fused && s->A->fmt == 
 template <int MODE> static void scalar_launch(sb_cg* s, int defer_x = 0)
 {
   hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
-      s->S, s->rr_hist, s->pAp_hist, g.comm ? 1 : 0, defer_x);
+      s->S, s->rr_hist, s->pAp_hist, multi_rank() ? 1 : 0, defer_x);
   HIP_CHECK(hipGetLastError());
-  if (g.comm) {
+  if (multi_rank()) {
     mark(s, R_DDOT);
     sb_comm_reduction(&s->S->local, 1);
     mark(s, R_COMM);
@@ -1247,7 +1273,7 @@ static void ensure_hist(sb_cg* s, int cap)
 
 static void run_body_maybe_graph(sb_cg* s, int k)
 { // k >= 2 bodies are iteration-invariant (k lives in the device control block)
-  if (k < 2 || !s->use_graph || g.comm || s->timing || s->spmvTiming) {
+  if (k < 2 || !s->use_graph || multi_rank() || s->timing || s->spmvTiming) {
     loop_body(s, k);
     return;
   }
@@ -1377,7 +1403,7 @@ double sb_cg_check_residual(const sb_cg* s)
   double m = 0.0;
   for (double v : h)
     if (v > m) m = v;
-  if (g.comm) { // commReduction(&residual, MAX), src/CGSolver.c:55
+  if (multi_rank()) { // commReduction(&residual, MAX), src/CGSolver.c:55
     sb_h2d(g.scalar, &m, sizeof m);
     sb_comm_reduction(g.scalar, 0);
     sb_d2h(&m, g.scalar, sizeof m);

@@ -1,0 +1,40 @@
+"""The N-rank DEVICE path on one GPU: several processes (one rank each) share GPU 0 and
+talk through a host-mediated gloo transport instead of RCCL (see
+tests/gpu_multirank_worker.py).  Covers what the 1-GPU box cannot reach with RCCL: halo
+pack indices through the SCS permutation, halo columns in the compressed stream / LDS
+windows, received entries landing in the tail of p, the split local-reduce / all-reduce /
+scalar-step sequence, and the device-side loop exit on every rank."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("fmt,Cc,sigma,n,size,itermax", [
+    ("scs", 64, 256, 16, 2, 100),   # permuted rows, compressed stream + LDS windows with halo segments
+    ("scs", 64, 1, 16, 4, 100),     # interior ranks with two neighbours
+    ("crs", 64, 1, 16, 2, 100),
+    ("scs", 4, 8, 8, 3, 40),        # generic-C kernel, odd rank count
+])
+def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(size),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "gpu_multirank_worker.py"), fmt, str(Cc), str(sigma), str(n), str(itermax)]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-4000:]
+    assert "GPU_MULTIRANK_OK %s %d %d %d %d" % (fmt, Cc, sigma, n, size) in text, text[-3000:]
