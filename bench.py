@@ -125,8 +125,9 @@ def main():
     ap.add_argument("--C", type=int, default=64)
     ap.add_argument("--sigma", type=int, default=256)
     ap.add_argument("--graph", type=int, default=0)
-    ap.add_argument("--pack-mode", type=int, default=2,
-                    help="SpMV stream: 0 reference layout, 1 compressed, 2 compressed + LDS x-window (default: best available)")
+    ap.add_argument("--pack-mode", type=int, default=3,
+                    help="SpMV stream: 0 reference layout, 1 compressed, 2 compressed + LDS x-window, "
+                         "3 pattern codes + LDS x-window (default: best available)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=60)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
@@ -230,7 +231,7 @@ def main():
         prob.use_packed(mode)
         ref_leg = (t_ref, ref_ms, ref_n)
     else:
-        moved_bytes, pack = prob.stream_bytes(), {"level": 0, "mode": 0, "lds_window_doubles": 0}
+        moved_bytes, pack = prob.stream_bytes(), {"level": 0, "mode": 0, "lds_window_doubles": 0, "pattern_classes": 0}
     if dist is not None:
         import torch
         tt = torch.tensor([t_clean], dtype=torch.float64)
@@ -261,7 +262,7 @@ def main():
             "cg_frac_of_hbm_peak": cg_bytes * it_s / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm",
                          "kernel": ("spmv_crs_stream" if args.fmt == "crs" else
-                                    ["spmv_scs64", "spmv_scs64_packed", "spmv_scs64_lds"][mode]),
+                                    ["spmv_scs64", "spmv_scs64_packed", "spmv_scs64_lds", "spmv_scs64_pat"][mode]),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": spmv_bytes,

@@ -85,11 +85,14 @@ double sb_matrix_spmv_bytes(const sb_matrix* m);
 int sb_matrix_pack_level(const sb_matrix* m);
 /* select the SpMV kernel at run time: 0 reference-layout stream, 1 packed stream with x
  * gathered through the cache, 2 packed stream with each workgroup's x window staged in LDS
- * (built when every tile's window fits; SB_PACK=2 stops at mode 1).  Clamped to what the
- * matrix has; default = the highest available. */
+ * (built when every tile's window fits; SB_PACK=2 stops at mode 1), 3 one-byte pattern
+ * codes naming (value, window-slot delta) pairs + LDS window (built when every tile has
+ * <= 255 distinct pairs; SB_PACK=3 stops at mode 2).  Clamped to what the matrix has;
+ * default = the highest available.  All modes give bit-identical results. */
 void sb_matrix_use_packed(sb_matrix* m, int mode);
 int sb_matrix_packed_mode(const sb_matrix* m);
 uint32_t sb_matrix_lds_window(const sb_matrix* m); /* doubles per workgroup, 0 if not built */
+uint32_t sb_matrix_pattern_classes(const sb_matrix* m); /* pattern tables built (mode 3), 0 if none */
 /* bytes the selected SpMV kernel really moves per launch (stream + x + y) */
 double sb_matrix_stream_bytes(const sb_matrix* m);
 

@@ -338,4 +338,248 @@ __global__ __launch_bounds__(256) void spmv_scs64_lds(const PackMeta* __restrict
   spmv_epilogue<DOT>(chunk, lane, acc, x, y, nr, dotPartials);
 }
 
+// ---- level 4: pattern dictionary ---------------------------------------------------------
+// In the LDS-window kernel an element costs 3 B (value code + 16-bit slot).  In a matrix
+// with repeating row patterns (any stencil; any mesh numbered line by line) the PAIR
+// (value, slot - slot of the row's first element) takes few distinct values per tile, so
+// one byte can name the pair.  Per tile the device collects its distinct pairs; the host
+// merges tiles into classes of <= 255 pairs (a 27-point stencil on one GPU: one or a
+// handful of classes); a workgroup stages its class's table (4 KiB: value, delta, mask)
+// next to the x window and per element does
+//        e = table[code];   acc = acc + e.v * sx[(rowBase & e.mask) + e.delta]
+// rowBase is a 16-bit slot per row; padding keeps its reference meaning through
+// mask = 0, delta = 0 (slot 0 = x[padCol]).  1 B per element instead of 3, still lossless,
+// same order, same bits.  Any tile with > 255 pairs: the matrix stays at level 3.
+struct PatEntry {
+  double v;
+  int32_t delta;
+  uint32_t mask;
+};
+
+constexpr uint32_t PAT_ABS   = 0x01000000u; // key bit: absolute slot 0 (padding)
+constexpr uint32_t PAT_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t PAT_MAX   = 255u;        // pairs per class
+
+__device__ __forceinline__ uint32_t pat_key(uint32_t slot, uint32_t base, uint32_t vcode)
+{
+  return slot == 0u ? (PAT_ABS | vcode) : (vcode | (((slot - base + 32768u) & 0xFFFFu) << 8));
+}
+
+// slot / value code of element (row `lane`, column j) from the level-3 streams
+__device__ __forceinline__ void pat_fetch(const uint32_t* __restrict__ slots,
+    const uint32_t* __restrict__ codes, const PackMeta& m, uint32_t lane, uint32_t j, uint32_t& slot,
+    uint32_t& vcode)
+{
+  const size_t p    = ((size_t)(m.grp + (j >> 2)) * 64 + lane);
+  const uint32_t sw = slots[p * 2 + ((j >> 1) & 1u)];
+  slot              = (j & 1u) ? sw >> 16 : sw & 0xFFFFu;
+  vcode             = (codes[p] >> (8u * (j & 3u))) & 255u;
+}
+
+__global__ __launch_bounds__(256) void pat_collect_k(const PackMeta* __restrict__ meta,
+    const uint32_t* __restrict__ slots, const uint32_t* __restrict__ codes, uint32_t nChunks,
+    uint16_t* __restrict__ rowBase, uint32_t* __restrict__ tileCount, uint32_t* __restrict__ tileKeys)
+{
+  __shared__ uint32_t table[1024];
+  __shared__ uint32_t count, outPos;
+  const uint32_t tile  = blockIdx.x;
+  const uint32_t chunk = tile * 4u + (threadIdx.x >> 6);
+  const uint32_t lane  = threadIdx.x & 63u;
+  for (uint32_t i = threadIdx.x; i < 1024u; i += 256u) table[i] = PAT_EMPTY;
+  if (threadIdx.x == 0) count = 0u, outPos = 0u;
+  __syncthreads();
+  if (chunk < nChunks) {
+    const PackMeta m   = meta[chunk];
+    const uint32_t len = m.info & 0x7FFFFFFFu;
+    uint32_t base = 0u, vc;
+    if (len) pat_fetch(slots, codes, m, lane, 0u, base, vc);
+    rowBase[(size_t)chunk * 64 + lane] = (uint16_t)base;
+    for (uint32_t j = 0; j < len; j++) {
+      uint32_t slot, vcode;
+      pat_fetch(slots, codes, m, lane, j, slot, vcode);
+      const uint32_t key = pat_key(slot, base, vcode);
+      uint32_t h         = (key * 2654435761u) >> 22; // 10 bits
+      // every thread re-reads count before probing, so the table (1024) never fills:
+      // at most PAT_MAX + 256 distinct keys get in
+      while (*(volatile uint32_t*)&count <= PAT_MAX) {
+        const uint32_t old = atomicCAS(&table[h], PAT_EMPTY, key);
+        if (old == PAT_EMPTY) {
+          atomicAdd(&count, 1u);
+          break;
+        }
+        if (old == key) break;
+        h = (h + 1u) & 1023u;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) tileCount[tile] = count;
+  if (count <= PAT_MAX)
+    for (uint32_t i = threadIdx.x; i < 1024u; i += 256u)
+      if (table[i] != PAT_EMPTY) tileKeys[(size_t)tile * 256 + atomicAdd(&outPos, 1u)] = table[i];
+}
+
+__global__ __launch_bounds__(256) void pat_encode_k(const PackMeta* __restrict__ meta,
+    const uint32_t* __restrict__ slots, const uint32_t* __restrict__ codes, uint32_t nChunks,
+    const uint16_t* __restrict__ rowBase, const uint32_t* __restrict__ tileClass,
+    const uint32_t* __restrict__ classKeys, uint32_t* __restrict__ jcodes)
+{
+  __shared__ uint32_t keys[256]; // ascending, padded with PAT_EMPTY
+  const uint32_t tile  = blockIdx.x;
+  const uint32_t chunk = tile * 4u + (threadIdx.x >> 6);
+  const uint32_t lane  = threadIdx.x & 63u;
+  keys[threadIdx.x]    = classKeys[(size_t)tileClass[tile] * 256 + threadIdx.x];
+  __syncthreads();
+  if (chunk >= nChunks) return;
+  const PackMeta m    = meta[chunk];
+  const uint32_t len  = m.info & 0x7FFFFFFFu;
+  const uint32_t base = rowBase[(size_t)chunk * 64 + lane];
+  const uint32_t ng   = (len + 3u) >> 2;
+  for (uint32_t g = 0; g < ng; g++) {
+    uint32_t word = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t j = g * 4u + k;
+      if (j < len) {
+        uint32_t slot, vcode;
+        pat_fetch(slots, codes, m, lane, j, slot, vcode);
+        const uint32_t key = pat_key(slot, base, vcode);
+        uint32_t lo = 0u, hi = 255u; // the key is present by construction
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (keys[mid] < key) lo = mid + 1u;
+          else hi = mid;
+        }
+        word |= lo << (8u * k);
+      }
+    }
+    jcodes[(size_t)(m.grp + g) * 64 + lane] = word;
+  }
+}
+
+// Everything a workgroup needs to know about its tile, in one 128-byte record: the kernel
+// is latency-bound (each of the 4 rounds of tiles a CU runs pays every DEPENDENT memory
+// round trip once), so header -> {codes, row bases, pattern table, x window} is the
+// whole chain: two round trips, everything else in parallel.
+constexpr uint32_t PAT_INLINE_SEGS = 6;
+struct TileHdr {
+  uint32_t cls;       // pattern class
+  uint32_t nseg;      // segments of the window
+  uint32_t segPtr;    // first segment in the global list (tiles with > PAT_INLINE_SEGS)
+  uint32_t win;       // window entries incl. slot 0
+  uint32_t grp[4];    // code-stream position (groups of 4 columns) of the tile's chunks
+  uint32_t len[4];    // chunk widths (0 for chunks past the end)
+  uint32_t seg[PAT_INLINE_SEGS][3]; // first column, first slot (0xFFFFFFFF: unused), entries
+  uint32_t winInline; // window entries covered by the inline segments
+  uint32_t pad_;
+};
+static_assert(sizeof(TileHdr) == 128, "TileHdr is one 128-byte record");
+
+template <bool DOT>
+__global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict__ hdrs,
+    const uint32_t* __restrict__ jcodes, const uint16_t* __restrict__ rowBase,
+    const PatEntry* __restrict__ classDict, const TileSeg* __restrict__ segs,
+    const double* __restrict__ x, double* __restrict__ y, uint32_t nr, uint32_t nChunks,
+    uint32_t blocksPerXcd, uint32_t padCol, double* __restrict__ dotPartials,
+    const int* __restrict__ stop)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[]; // [256 PatEntry][window]
+  PatEntry* sd = reinterpret_cast<PatEntry*>(lds);
+  double* sx   = lds + 512;
+  constexpr int PF = 8; // code groups prefetched (32 columns); wider chunks stream the rest
+  constexpr int WB = 8; // window entries per thread and pass
+  const uint32_t nTiles = (nChunks + 3u) >> 2;
+  const uint32_t tile0  = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
+  const uint32_t tile   = min(tile0, nTiles - 1u); // clamped: every load below is unconditional
+  // round trip 1: ONE vector load brings the tile header (lanes 0..31) and the stop flag
+  // (lane 32); fields are then read out of the lanes (v_readlane -> SGPRs)
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t* hp  = reinterpret_cast<const uint32_t*>(hdrs + tile);
+  const uint32_t hv   = *(lane < 32u ? hp + lane : reinterpret_cast<const uint32_t*>(stop));
+  uint32_t H[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) H[i] = (uint32_t)__builtin_amdgcn_readlane((int)hv, i);
+  const int stopped    = __builtin_amdgcn_readlane((int)hv, 32);
+  const uint32_t wv    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t chunk = tile * 4u + wv;
+  const uint32_t row   = chunk * 64u + lane;
+  const bool active    = chunk < nChunks; // wave-uniform; inactive waves still help staging
+  const uint32_t grp   = (uint32_t)__builtin_amdgcn_readlane((int)hv, 4 + (int)wv);
+  const uint32_t len   = (uint32_t)__builtin_amdgcn_readlane((int)hv, 8 + (int)wv);
+  const uint32_t ng    = (len + 3u) >> 2;
+  const uint32_t cls = H[0], nseg = H[1], segPtr = H[2], winInline = H[30];
+  // round trip 2: code stream, row bases, own x entries, pattern table, x window -- all
+  // addresses clamped into valid memory so that nothing waits for a branch
+  const uint32_t* cstream = jcodes + (size_t)grp * 64 + lane;
+  const uint32_t gLast    = ng ? ng - 1u : 0u;
+  uint32_t cw[PF];
+#pragma unroll
+  for (int gi = 0; gi < PF; gi++) cw[gi] = stream_load(cstream + (size_t)min((uint32_t)gi, gLast) * 64);
+  const int32_t base  = (int32_t)rowBase[active ? row : 0u];
+  const double xrow   = DOT ? x[min(row, nr - 1u)] : 0.0;
+  const PatEntry mine = classDict[(size_t)cls * 256 + threadIdx.x];
+  double t[WB];
+#pragma unroll
+  for (int k = 0; k < WB; k++) { // first (normally only) pass over the window
+    const uint32_t slot = min((uint32_t)k * 256u + threadIdx.x, winInline - 1u);
+    uint32_t col        = padCol; // slot 0: what padding multiplies (src/matrix-SCS.c:151-155)
+#pragma unroll
+    for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++)
+      col = slot >= H[12 + 3 * s + 1] ? H[12 + 3 * s] + (slot - H[12 + 3 * s + 1]) : col;
+    t[k] = x[col];
+  }
+  // keep every load above in front of the exit test (the compiler would sink them behind it)
+  asm volatile("" ::"v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]));
+  asm volatile("" ::"v"(cw[0]), "v"(cw[1]), "v"(cw[2]), "v"(cw[3]), "v"(cw[4]), "v"(cw[5]), "v"(cw[6]),
+               "v"(cw[7]), "v"(base), "v"(xrow), "v"(mine.v), "v"(mine.delta), "v"(mine.mask));
+  if (tile0 >= nTiles || stopped) return; // uniform per workgroup
+#pragma unroll
+  for (int k = 0; k < WB; k++) {
+    const uint32_t slot = (uint32_t)k * 256u + threadIdx.x;
+    if (slot < winInline) sx[slot] = t[k];
+  }
+  for (uint32_t w0 = 256u * WB; w0 < winInline; w0 += 256u) { // windows > 2048 entries
+    const uint32_t slot = w0 + threadIdx.x;
+    uint32_t col        = padCol;
+#pragma unroll
+    for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++)
+      col = slot >= H[12 + 3 * s + 1] ? H[12 + 3 * s] + (slot - H[12 + 3 * s + 1]) : col;
+    if (slot < winInline) sx[slot] = x[col];
+  }
+  for (uint32_t s = PAT_INLINE_SEGS; s < nseg; s++) { // rare: tiles with many ranges
+    const TileSeg sg = segs[segPtr + s];
+    for (uint32_t i = threadIdx.x; i < sg.len; i += 256u) sx[sg.lds + i] = x[sg.col + i];
+  }
+  sd[threadIdx.x] = mine;
+  __syncthreads();
+  if (!active) return;
+  // accumulate left to right; the 4 table reads and then the 4 x reads of a group are in
+  // flight together, columns past the chunk's width are computed but not added
+  double acc = 0.0;
+  auto group = [&](uint32_t cwv, uint32_t j0) {
+    PatEntry e[4];
+    double xs[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) e[k] = sd[(cwv >> (8u * k)) & 255u];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) xs[k] = sx[(base & (int32_t)e[k].mask) + e[k].delta];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      const double prod = e[k].v * xs[k];
+      const double sum  = acc + prod;
+      acc               = (j0 + k < len) ? sum : acc; // wave-uniform select
+    }
+  };
+#pragma unroll
+  for (int gi = 0; gi < PF; gi++)
+    if ((uint32_t)gi < ng) group(cw[gi], (uint32_t)gi * 4u);
+  for (uint32_t g = PF; g < ng; g++) group(stream_load(cstream + (size_t)g * 64), g * 4u);
+  if (row < nr) y[row] = acc;
+  if (DOT) {
+    double t = row < nr ? xrow * acc : 0.0;
+    t        = butterfly64(t);
+    if (lane == 0) dotPartials[chunk] = t;
+  }
+}
+
 } // namespace sbk

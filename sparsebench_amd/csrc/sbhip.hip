@@ -19,6 +19,7 @@
 #include "pack.hip.h"
 
 #include <algorithm>
+#include <iterator>
 
 using namespace sbk;
 
@@ -115,6 +116,9 @@ struct Ctx {
 } g;
 
 inline bool multi_rank() { return g.comm != nullptr || g.hasXport; }
+// a stop flag that is never set, for launches outside a CG loop (kernels that fetch the flag
+// together with other data want a valid address)
+inline const int* zero_flag() { return reinterpret_cast<const int*>(g.scalar + 4); }
 
 void need_init()
 {
@@ -180,6 +184,13 @@ struct sb_matrix {
   uint32_t* pslots     = nullptr;
   uint32_t ldsWindow   = 0; // doubles, incl. slot 0
   double slotBytes     = 0.0;
+  // level 4: pattern dictionary (one byte per element)
+  uint16_t* rowBase     = nullptr;
+  uint32_t *tileClass = nullptr, *jcodes = nullptr;
+  PatEntry* classDict   = nullptr;
+  TileHdr* tileHdrs     = nullptr;
+  uint32_t nPatClasses  = 0;
+  double patBytes       = 0.0;
 };
 
 struct sb_halo {
@@ -250,6 +261,7 @@ void sb_init(int device)
   snprintf(g.name, sizeof g.name, "%s (%s)", g.prop.name[0] ? g.prop.name : "AMD Instinct", g.prop.gcnArchName);
   HIP_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
   HIP_CHECK(hipMalloc(&g.scalar, 64));
+  HIP_CHECK(hipMemset(g.scalar, 0, 64)); // [0] scratch double, [4] a permanent int 0 (zero_flag)
   g.device = device;
   g.init   = true;
 }
@@ -571,6 +583,114 @@ static void build_lds_windows(sb_matrix* m, const uint32_t* chunkPtr, const uint
   m->usePacked = 2; // 2: packed stream + x window in LDS
 }
 
+// Level 4: one byte per element naming a (value, slot delta) pair of the tile's class
+// (pack.hip.h).  Needs the value dictionary and the LDS windows.
+static void build_patterns(sb_matrix* m)
+{
+  if (m->usePacked != 2 || m->nDict <= 0) return;
+  const char* env = getenv("SB_PACK");
+  if ((env ? atoi(env) : 4) < 4) return;
+  const uint32_t nTiles = (m->nChunks + 3) / 4;
+  uint32_t *dCount = nullptr, *dKeys = nullptr;
+  HIP_CHECK(hipMalloc(&m->rowBase, (size_t)m->nChunks * 64 * sizeof(uint16_t) + 16));
+  HIP_CHECK(hipMalloc(&dCount, (size_t)nTiles * sizeof(uint32_t)));
+  HIP_CHECK(hipMalloc(&dKeys, (size_t)nTiles * 256 * sizeof(uint32_t)));
+  hipLaunchKernelGGL(pat_collect_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, m->pslots, m->pcodes,
+      m->nChunks, m->rowBase, dCount, dKeys);
+  HIP_CHECK(hipGetLastError());
+  std::vector<uint32_t> count(nTiles), keys((size_t)nTiles * 256);
+  sb_d2h(count.data(), dCount, count.size() * sizeof(uint32_t));
+  sb_d2h(keys.data(), dKeys, keys.size() * sizeof(uint32_t));
+  HIP_CHECK(hipFree(dCount));
+  HIP_CHECK(hipFree(dKeys));
+  auto giveUp = [&]() { sb_free(m->rowBase), m->rowBase = nullptr; };
+  for (uint32_t t = 0; t < nTiles; t++)
+    if (count[t] > PAT_MAX) return giveUp();
+  // tiles -> classes of <= PAT_MAX pairs: a class that already holds the tile's pairs,
+  // else the first class the pairs still fit into, else a new class
+  std::vector<std::vector<uint32_t>> classes;
+  std::vector<uint32_t> tileClass(nTiles, 0), merged;
+  const size_t maxClasses = std::max<size_t>(64, nTiles / 4);
+  uint32_t lastClass = 0;
+  for (uint32_t t = 0; t < nTiles; t++) {
+    uint32_t* k = keys.data() + (size_t)t * 256;
+    std::sort(k, k + count[t]);
+    int found = -1;
+    if (!classes.empty() && std::includes(classes[lastClass].begin(), classes[lastClass].end(), k, k + count[t]))
+      found = (int)lastClass;
+    for (size_t c = 0; found < 0 && c < classes.size(); c++)
+      if (std::includes(classes[c].begin(), classes[c].end(), k, k + count[t])) found = (int)c;
+    for (size_t c = 0; found < 0 && c < classes.size(); c++) {
+      merged.clear();
+      std::set_union(classes[c].begin(), classes[c].end(), k, k + count[t], std::back_inserter(merged));
+      if (merged.size() <= PAT_MAX) classes[c] = merged, found = (int)c;
+    }
+    if (found < 0) {
+      if (classes.size() >= maxClasses) return giveUp(); // no repeating patterns: not worth the tables
+      classes.emplace_back(k, k + count[t]);
+      found = (int)classes.size() - 1;
+    }
+    tileClass[t] = lastClass = (uint32_t)found;
+  }
+  if (classes.empty()) classes.emplace_back();
+  std::vector<double> dict(256);
+  sb_d2h(dict.data(), m->pdict, 256 * sizeof(double));
+  std::vector<uint32_t> classKeys(classes.size() * 256, PAT_EMPTY);
+  std::vector<PatEntry> classDict(classes.size() * 256, PatEntry{ 0.0, 0, 0u });
+  for (size_t c = 0; c < classes.size(); c++)
+    for (size_t i = 0; i < classes[c].size(); i++) {
+      const uint32_t key       = classes[c][i];
+      classKeys[c * 256 + i]   = key;
+      PatEntry& e              = classDict[c * 256 + i];
+      e.v                      = dict[key & 255u];
+      if (key & PAT_ABS) e.delta = 0, e.mask = 0u;
+      else e.delta = (int32_t)((key >> 8) & 0xFFFFu) - 32768, e.mask = 0xFFFFFFFFu;
+    }
+  uint32_t* dClassKeys = (uint32_t*)upload(classKeys.data(), classKeys.size() * sizeof(uint32_t));
+  m->tileClass         = (uint32_t*)upload(tileClass.data(), tileClass.size() * sizeof(uint32_t));
+  m->classDict         = (PatEntry*)upload(classDict.data(), classDict.size() * sizeof(PatEntry));
+  std::vector<PackMeta> meta(m->nChunks);
+  sb_d2h(meta.data(), m->pmeta, meta.size() * sizeof(PackMeta));
+  const uint64_t groups = (uint64_t)meta.back().grp + ((meta.back().info & 0x7FFFFFFFu) + 3u) / 4u;
+  HIP_CHECK(hipMalloc(&m->jcodes, (size_t)groups * 256 + 1024));
+  hipLaunchKernelGGL(pat_encode_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, m->pslots, m->pcodes,
+      m->nChunks, m->rowBase, m->tileClass, dClassKeys, m->jcodes);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  HIP_CHECK(hipFree(dClassKeys));
+  m->nPatClasses = (uint32_t)classes.size();
+  // one 128-byte header per tile: class, chunk positions / widths, the first segments
+  std::vector<uint32_t> segPtr(nTiles + 1);
+  sb_d2h(segPtr.data(), m->tileSegPtr, segPtr.size() * sizeof(uint32_t));
+  const size_t nSegs = segPtr[nTiles];
+  std::vector<TileSeg> segs(std::max<size_t>(nSegs, 1));
+  if (nSegs) sb_d2h(segs.data(), m->tileSegs, nSegs * sizeof(TileSeg));
+  std::vector<TileHdr> hdrs(nTiles);
+  for (uint32_t t = 0; t < nTiles; t++) {
+    TileHdr& h = hdrs[t];
+    memset(&h, 0, sizeof h);
+    h.cls = tileClass[t], h.nseg = segPtr[t + 1] - segPtr[t], h.segPtr = segPtr[t], h.win = 1;
+    for (uint32_t w = 0; w < 4; w++) {
+      const uint32_t c = t * 4 + w;
+      if (c < m->nChunks) h.grp[w] = meta[c].grp, h.len[w] = meta[c].info & 0x7FFFFFFFu;
+    }
+    for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++) h.seg[s][1] = 0xFFFFFFFFu;
+    h.winInline = 1;
+    for (uint32_t s = 0; s < h.nseg; s++) {
+      const TileSeg& sg = segs[segPtr[t] + s];
+      if (s < PAT_INLINE_SEGS) {
+        h.seg[s][0] = sg.col, h.seg[s][1] = sg.lds, h.seg[s][2] = sg.len;
+        h.winInline = sg.lds + sg.len;
+      }
+      h.win = sg.lds + sg.len;
+    }
+  }
+  m->tileHdrs = (TileHdr*)upload(hdrs.data(), hdrs.size() * sizeof(TileHdr));
+  m->patBytes  = (double)groups * 256.0 + 2.0 * 64.0 * m->nChunks + 16.0 * m->nChunks + 16.0 * nSegs +
+                 128.0 * nTiles + 4096.0 * classes.size();
+  m->usePacked = 3; // 3: pattern codes + x window in LDS
+}
+
 sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, uint32_t nChunks,
     uint32_t nElems, const uint32_t* chunkPtr, const uint32_t* chunkLens, const uint32_t* colInd,
     const double* val, const uint32_t* oldToNewPerm, const uint32_t* newToOldPerm)
@@ -617,6 +737,7 @@ sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, u
   }
   build_packed(m, val, oldToNewPerm);
   build_lds_windows(m, chunkPtr, chunkLens, colInd, val, oldToNewPerm);
+  build_patterns(m);
   return m;
 }
 
@@ -627,20 +748,25 @@ void sb_matrix_free(sb_matrix* m)
   sb_free(m->oldToNew), sb_free(m->newToOld), sb_free(m->colInd), sb_free(m->val);
   sb_free(m->pmeta), sb_free(m->pidx), sb_free(m->pcodes), sb_free(m->pdict);
   sb_free(m->tileSegPtr), sb_free(m->tileSegs), sb_free(m->pslots);
+  sb_free(m->rowBase), sb_free(m->tileClass), sb_free(m->jcodes), sb_free(m->classDict), sb_free(m->tileHdrs);
   delete m;
 }
 
 int sb_matrix_pack_level(const sb_matrix* m) { return m->packLevel; }
 void sb_matrix_use_packed(sb_matrix* m, int mode)
-{ // 0 reference-layout stream, 1 packed stream + gathers through the cache, 2 packed + LDS window
-  if (mode >= 2 && m->ldsWindow) m->usePacked = 2;
+{ // 0 reference-layout stream, 1 packed stream + gathers through the cache, 2 packed + LDS window,
+  // 3 pattern codes + LDS window; a mode the matrix does not have falls to the next lower one
+  if (mode >= 3 && m->nPatClasses) m->usePacked = 3;
+  else if (mode >= 2 && m->ldsWindow) m->usePacked = 2;
   else if (mode >= 1 && m->packLevel) m->usePacked = 1;
   else m->usePacked = 0;
 }
 int sb_matrix_packed_mode(const sb_matrix* m) { return m->usePacked; }
 uint32_t sb_matrix_lds_window(const sb_matrix* m) { return m->ldsWindow; }
+uint32_t sb_matrix_pattern_classes(const sb_matrix* m) { return m->nPatClasses; }
 double sb_matrix_stream_bytes(const sb_matrix* m)
 { // bytes the SELECTED SpMV kernel moves per launch (matrix stream + x once + y once)
+  if (m->fmt == 1 && m->usePacked == 3) return m->patBytes + 8.0 * m->nrPadded + 8.0 * m->nc;
   if (m->fmt == 1 && m->usePacked == 2) return m->slotBytes + 8.0 * m->nrPadded + 8.0 * m->nc;
   if (m->fmt == 1 && m->usePacked) return m->packedBytes + 8.0 * m->nrPadded + 8.0 * m->nc;
   return sb_matrix_spmv_bytes(m);
@@ -685,7 +811,16 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
     const uint32_t nBlocks = (m->nChunks + 3) / 4;
     const uint32_t per     = g_scs_xcd ? (nBlocks + 7) / 8 : 0;
     dim3 grid(g_scs_xcd ? per * 8 : nBlocks), block(256);
-    if (m->usePacked == 2) {
+    if (m->usePacked == 3) {
+      const size_t shmem = (512 + (size_t)m->ldsWindow) * sizeof(double);
+      if (!stop) stop = zero_flag();
+      if (dot)
+        hipLaunchKernelGGL((spmv_scs64_pat<true>), grid, block, shmem, g.stream, m->tileHdrs, m->jcodes,
+            m->rowBase, m->classDict, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol, dotPartials, stop);
+      else
+        hipLaunchKernelGGL((spmv_scs64_pat<false>), grid, block, shmem, g.stream, m->tileHdrs, m->jcodes,
+            m->rowBase, m->classDict, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol, dotPartials, stop);
+    } else if (m->usePacked == 2) {
       const size_t shmem = (256 + (size_t)m->ldsWindow) * sizeof(double);
 #define LDS_LAUNCH(DI, DO)                                                                                   \
   hipLaunchKernelGGL((spmv_scs64_lds<DI, DO>), grid, block, shmem, g.stream, m->pmeta, m->pslots, m->pcodes, \

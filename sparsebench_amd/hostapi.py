@@ -145,7 +145,8 @@ class Problem:
     def pack_info(self):
         L = capi.load()
         return {"level": L.sb_matrix_pack_level(self.matrix), "mode": L.sb_matrix_packed_mode(self.matrix),
-                "lds_window_doubles": L.sb_matrix_lds_window(self.matrix)}
+                "lds_window_doubles": L.sb_matrix_lds_window(self.matrix),
+                "pattern_classes": L.sb_matrix_pattern_classes(self.matrix)}
 
     def free(self):
         if self.ptr:

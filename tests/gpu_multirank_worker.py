@@ -107,7 +107,7 @@ def main():
     plans = po.Plans(locs)
     o = po.cg(locs, plans, itermax=itermax, fmt=fmt, Cc=Cc, sigma=sigma, dot="tree", rank_sum="tree", want_x=True)
     results = {}
-    for mode in ((2, 1, 0) if fmt == "scs" and Cc == 64 else (0,)):
+    for mode in ((3, 2, 1, 0) if fmt == "scs" and Cc == 64 else (0,)):
         if fmt == "scs":
             prob.use_packed(mode)
         for fused in (True, False):

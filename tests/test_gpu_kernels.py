@@ -39,13 +39,18 @@ def gpu_spmv(L, m, x, nr):
     y = dy.get()
     if L.sb_matrix_pack_level(m) > 0:
         best = L.sb_matrix_packed_mode(m)
-        assert best == (2 if L.sb_matrix_lds_window(m) else 1)
-        for mode in (0, 1, 2):  # reference stream / packed + cache gathers / packed + LDS window
+        assert best == (3 if L.sb_matrix_pattern_classes(m) else 2 if L.sb_matrix_lds_window(m) else 1)
+        # reference stream / packed + cache gathers / packed + LDS window / pattern codes + LDS window
+        for mode in (0, 1, 2, 3):
             L.sb_matrix_use_packed(m, mode)
             dy.set(np.full(nr, 7.0))
             L.sb_spmv(m, dx.ptr, dy.ptr)
             y2 = dy.get()
-            assert np.array_equal(y.view(np.uint64), y2.view(np.uint64)), "kernel mode %d differs" % mode
+            # bit-identical; where the result is NaN only the NaN-ness is compared (which NaN
+            # payload an add of two NaNs returns depends on operand order, not on the algorithm)
+            nan = np.isnan(y)
+            assert np.array_equal(nan, np.isnan(y2)), "kernel mode %d: NaN rows differ" % mode
+            assert np.array_equal(y[~nan].view(np.uint64), y2[~nan].view(np.uint64)), "kernel mode %d differs" % mode
         L.sb_matrix_use_packed(m, best)
     dx.free(), dy.free()
     return y
@@ -168,6 +173,69 @@ def test_packed_stream_levels_and_wide_chunks(gpu):
         got, exp = gpu_spmv(L, m, x, nr), gm.spmv(x)
         assert np.array_equal(got.view(np.uint64), exp.view(np.uint64))
         L.sb_matrix_free(m)
+
+
+def test_pattern_dictionary_mode(gpu, monkeypatch):
+    """mode 3 (one byte per element naming a (value, slot delta) pair): built for stencils
+    with and without the sigma permutation, refused when a tile has > 255 distinct pairs,
+    bit-identical to the oracle in every case (gpu_spmv compares all four kernels)"""
+    L = gpu
+    rng = np.random.default_rng(29)
+    # sigma > 1 on SMALL grids scatters a tile's rows over many lines: > 255 pairs per tile, the
+    # matrix then stays at mode 2 (allowed); with 128-row lines (the headline shape) mode 3 is built
+    for dims, sg, must in (((16, 16, 16), 1, True), ((16, 16, 16), 256, False), ((9, 8, 7), 64, False),
+                           ((20, 5, 33), 4096, False), ((128, 128, 2), 256, True), ((70, 3, 5), 1, True)):
+        g = po.GMatrix.generate(*dims)
+        s = g.to_scs(64, sg)
+        m = upload_scs(L, s)
+        assert L.sb_matrix_lds_window(m) > 0
+        if must:
+            assert L.sb_matrix_pattern_classes(m) >= 1 and L.sb_matrix_packed_mode(m) == 3, (dims, sg)
+            L.sb_matrix_use_packed(m, 2)
+            lds_bytes = L.sb_matrix_stream_bytes(m)
+            L.sb_matrix_use_packed(m, 3)
+            assert L.sb_matrix_stream_bytes(m) < 0.62 * lds_bytes
+        x = rng.standard_normal(g.nc)
+        assert np.array_equal(gpu_spmv(L, m, x, g.nr), g.spmv(x))
+        # NaN / Inf in x reach exactly the rows the reference lets them reach (padding -> x[padCol])
+        x[0], x[g.nc // 2] = np.inf, np.nan
+        got, exp = gpu_spmv(L, m, x, g.nr), s.spmv(x)
+        assert np.isnan(exp).any() and np.array_equal(np.isnan(got), np.isnan(exp))
+        ok = ~np.isnan(exp)
+        assert np.array_equal(got[ok].view(np.uint64), exp[ok].view(np.uint64))
+        L.sb_matrix_free(m)
+    # banded matrix, 200 distinct values used round-robin: the LDS window is built (forced),
+    # but a tile holds far more than 255 (value, delta) pairs -> stays at mode 2
+    monkeypatch.setenv("SB_PACK_LDS", "1")
+    nr = 1024
+    rp = np.arange(0, 9 * nr + 1, 9, dtype=np.uint32)
+    col = (np.repeat(np.arange(nr), 9) + np.tile(np.arange(-4, 5), nr)).clip(0, nr - 1).astype(np.uint32)
+    val = (1.0 + (np.arange(9 * nr) * 7919 % 200)) * 0.125
+    gm = po.GMatrix.from_csr(rp, col, val, nc=nr)
+    s = gm.to_scs(64, 1)
+    m = upload_scs(L, s)
+    assert L.sb_matrix_lds_window(m) > 0 and L.sb_matrix_pattern_classes(m) == 0
+    assert L.sb_matrix_packed_mode(m) == 2
+    x = rng.standard_normal(nr)
+    assert np.array_equal(gpu_spmv(L, m, x, nr).view(np.uint64), gm.spmv(x).view(np.uint64))
+    L.sb_matrix_free(m)
+    # same band, 3 values by diagonal: patterns repeat -> mode 3; rows with duplicate columns
+    # (the clipped band ends) are separate elements and stay in order
+    val = np.tile(np.array([-1.0, -1.0, -0.5, -0.5, 8.0, -0.5, -0.5, -1.0, -1.0]), nr)
+    gm = po.GMatrix.from_csr(rp, col, val, nc=nr)
+    for sg in (1, 128):
+        s = gm.to_scs(64, sg)
+        m = upload_scs(L, s)
+        assert L.sb_matrix_pattern_classes(m) >= 1 and L.sb_matrix_packed_mode(m) == 3
+        assert np.array_equal(gpu_spmv(L, m, x, nr).view(np.uint64), gm.spmv(x).view(np.uint64))
+        L.sb_matrix_free(m)
+    monkeypatch.delenv("SB_PACK_LDS")
+    # SB_PACK=3 stops below the pattern level
+    monkeypatch.setenv("SB_PACK", "3")
+    g = po.GMatrix.generate(16, 16, 16)
+    m = upload_scs(L, g.to_scs(64, 1))
+    assert L.sb_matrix_pattern_classes(m) == 0 and L.sb_matrix_packed_mode(m) == 2
+    L.sb_matrix_free(m)
 
 
 def test_spmv_empty_matrix(gpu):
