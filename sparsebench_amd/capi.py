@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsbhip.so")
+LIB_PATH = os.environ.get("SBHIP_LIBRARY") or os.path.join(HERE, "lib", "libsbhip.so")  # override: lab builds
 
 # every symbol include/sbhip.h declares (tests check the .so exports all of them)
 SYMBOLS = [

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""pat_lab.py [n] [sigma] -- stand-alone timing of every SpMV kernel mode on the HPCG matrix
+(back-to-back launches, HIP events).  SBHIP_LIBRARY=<path> times a lab build of libsbhip.so
+(e.g. one compiled with -DSB_LAB=1 to knock out a phase of a kernel)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pyoracle as po  # noqa: E402  (matrix generation only)
+from sparsebench_amd import capi  # noqa: E402
+from sparsebench_amd.capi import DeviceVector  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+sigma = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+modes = [int(a) for a in sys.argv[3].split(",")] if len(sys.argv) > 3 else [3, 2, 1, 0]
+L = capi.init(0)
+g = po.GMatrix.generate(n, n, n)
+s = g.to_scs(64, sigma)
+arrs = [np.ascontiguousarray(a) for a in (s.chunkPtr, s.chunkLens, s.colInd, s.val, s.oldToNewPerm, s.newToOldPerm)]
+m = L.sb_scs_upload(s.nr, s.nc, 64, sigma, s.nChunks, s.nElems, *[a.ctypes.data_as(C.c_void_p) for a in arrs])
+x, y = DeviceVector.from_host(np.ones(s.nc)), DeviceVector(s.nr)
+for mode in modes:
+    L.sb_matrix_use_packed(m, mode)
+    if L.sb_matrix_packed_mode(m) != mode:
+        continue
+    for _ in range(5):
+        L.sb_spmv_native(m, x.ptr, y.ptr)
+    a, b = L.sb_event_create(), L.sb_event_create()
+    best = 1e9
+    for rep in range(3):
+        L.sb_event_record(a)
+        for _ in range(100):
+            L.sb_spmv_native(m, x.ptr, y.ptr)
+        L.sb_event_record(b)
+        best = min(best, 1e3 * L.sb_event_elapsed_ms(a, b) / 100)
+    print("%s mode %d: %.2f us  (moves %.1f MB)" % (os.environ.get("SBHIP_LIBRARY", "product"), mode, best,
+                                                   L.sb_matrix_stream_bytes(m) / 1e6))
