@@ -93,6 +93,9 @@ void sb_matrix_use_packed(sb_matrix* m, int mode);
 int sb_matrix_packed_mode(const sb_matrix* m);
 uint32_t sb_matrix_lds_window(const sb_matrix* m); /* doubles per workgroup, 0 if not built */
 uint32_t sb_matrix_pattern_classes(const sb_matrix* m); /* pattern tables built (mode 3), 0 if none */
+/* mode 3, level 5: distinct shared row patterns; *uniformChunks = chunks stored as one row
+ * pattern + exception lanes (the rest keep per-lane codes).  SB_PACK=4 builds none. */
+uint32_t sb_matrix_row_patterns(const sb_matrix* m, uint32_t* uniformChunks);
 /* bytes the selected SpMV kernel really moves per launch (stream + x + y) */
 double sb_matrix_stream_bytes(const sb_matrix* m);
 

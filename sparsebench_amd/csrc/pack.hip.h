@@ -457,64 +457,147 @@ __global__ __launch_bounds__(256) void pat_encode_k(const PackMeta* __restrict__
   }
 }
 
-// Everything a workgroup needs to know about its tile, in one 128-byte record: the kernel
-// is latency-bound (each of the 4 rounds of tiles a CU runs pays every DEPENDENT memory
-// round trip once), so header -> {codes, row bases, pattern table, x window} is the
-// whole chain: two round trips, everything else in parallel.
+// ---- level 5: row patterns -------------------------------------------------------------------
+// With one byte per element the kernel moves ~98 MB at 128^3 and is bound by its LDS phase
+// (16 B table entry + 8 B x per element and lane) and by the code stream.  But in a chunk of
+// 64 rows almost all rows carry the SAME code sequence (same values, same window-slot
+// deltas): a 27-point stencil chunk has 61-63 such rows and 1-3 odd ones (grid boundary,
+// rows the sigma sort moved).  So a chunk is stored as
+//     the offset of its dominant ROW PATTERN  -- len entries (value, delta, mask), shared by
+//                                                all chunks with that pattern (a handful)
+//     a 64-bit mask of exception lanes + the code sequences of those lanes only.
+// Dominant lanes take their entries from scalar registers (s_load through the scalar cache:
+// no LDS, no per-lane stream); exception lanes use their codes and the tile's table in LDS
+// as before and override per lane.  Chunks with many exceptions, or once the pattern table
+// is full, stay in the per-lane form (L chunks).  Lossless, same order, same bits.
 constexpr uint32_t PAT_INLINE_SEGS = 6;
+constexpr uint32_t PAT_UNIFORM     = 0x80000000u; // TileHdr.len[] flag: dominant-pattern chunk
+constexpr uint32_t PAT_EXC_MAX     = 24;          // more exception lanes than this: L chunk
+
+// Everything a workgroup needs to know about its tile, in one 192-byte record: the kernel is
+// latency-bound (a CU runs its tiles in 4 rounds and each round pays every DEPENDENT memory
+// round trip once), so header -> {codes, row bases, pattern table, x window} is the whole
+// chain: two round trips, everything else in parallel.
 struct TileHdr {
   uint32_t cls;       // pattern class
   uint32_t nseg;      // segments of the window
   uint32_t segPtr;    // first segment in the global list (tiles with > PAT_INLINE_SEGS)
   uint32_t win;       // window entries incl. slot 0
-  uint32_t grp[4];    // code-stream position (groups of 4 columns) of the tile's chunks
-  uint32_t len[4];    // chunk widths (0 for chunks past the end)
+  uint32_t off[4];    // code-stream position (words) of the tile's chunks
+  uint32_t len[4];    // chunk widths (0 for chunks past the end) | PAT_UNIFORM
   uint32_t seg[PAT_INLINE_SEGS][3]; // first column, first slot (0xFFFFFFFF: unused), entries
   uint32_t winInline; // window entries covered by the inline segments
   uint32_t pad_;
+  uint32_t rowPat[4]; // U chunks: first entry of the dominant row pattern
+  uint32_t exc[4][2]; // U chunks: exception lanes (lo, hi)
+  uint32_t pad2_[4];
 };
-static_assert(sizeof(TileHdr) == 128, "TileHdr is one 128-byte record");
+static_assert(sizeof(TileHdr) == 192, "TileHdr is 48 words");
+constexpr int PAT_STOP_LANE = 48; // the lane that fetches the stop flag next to the header
+
+// dominant code sequence of every chunk (majority of the 64 lanes) and the lanes that differ
+__global__ __launch_bounds__(256) void pat_dominant_k(const PackMeta* __restrict__ meta,
+    const uint32_t* __restrict__ jcodes, uint32_t nChunks, uint32_t* __restrict__ domCodes,
+    uint32_t* __restrict__ excMask)
+{
+  const uint32_t chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t lane  = threadIdx.x & 63u;
+  if (chunk >= nChunks) return;
+  const PackMeta m  = meta[chunk];
+  const uint32_t ng = ((m.info & 0x7FFFFFFFu) + 3u) >> 2;
+  const uint32_t* c = jcodes + (size_t)m.grp * 64 + lane;
+  uint32_t h        = 2166136261u;
+  for (uint32_t g = 0; g < ng; g++) h = (h ^ c[(size_t)g * 64]) * 16777619u;
+  uint32_t cnt = 0;
+  for (int k = 0; k < 64; k++) cnt += h == (uint32_t)__builtin_amdgcn_readlane((int)h, k);
+  uint32_t best = (cnt << 6) | (63u - lane); // most frequent hash, lowest lane on ties
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) best = max(best, (uint32_t)__shfl_xor((int)best, off, 64));
+  const int dom = 63 - (int)(best & 63u);
+  bool same     = true; // exact comparison with the dominant lane (a hash can collide)
+  for (uint32_t g = 0; g < ng; g++) {
+    const uint32_t w  = c[(size_t)g * 64];
+    const uint32_t wd = (uint32_t)__shfl((int)w, dom, 64);
+    same              = same && w == wd;
+    if (lane == 0) domCodes[m.grp + g] = wd;
+  }
+  const unsigned long long exc = __ballot(!same);
+  if (lane == 0) excMask[2 * (size_t)chunk] = (uint32_t)exc, excMask[2 * (size_t)chunk + 1] = (uint32_t)(exc >> 32);
+}
+
+// per-lane code words -> final stream: L chunks keep all 64 lanes (group-major), U chunks
+// only their exception lanes (lane-major: an exception lane's words are contiguous)
+__global__ __launch_bounds__(256) void pat_compact_k(const PackMeta* __restrict__ meta,
+    const uint32_t* __restrict__ jcodes, uint32_t nChunks, const uint32_t* __restrict__ chunkOff,
+    const uint32_t* __restrict__ chunkFlags, const uint32_t* __restrict__ excMask,
+    uint32_t* __restrict__ stream)
+{
+  const uint32_t chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t lane  = threadIdx.x & 63u;
+  if (chunk >= nChunks) return;
+  const PackMeta m   = meta[chunk];
+  const uint32_t ng  = ((m.info & 0x7FFFFFFFu) + 3u) >> 2;
+  const uint32_t* c  = jcodes + (size_t)m.grp * 64 + lane;
+  const uint32_t off = chunkOff[chunk];
+  if (chunkFlags[chunk] & PAT_UNIFORM) {
+    const uint32_t lo = excMask[2 * (size_t)chunk], hi = excMask[2 * (size_t)chunk + 1];
+    const bool isExc  = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
+    const uint32_t ix = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+    if (isExc)
+      for (uint32_t g = 0; g < ng; g++) stream[(size_t)off + (size_t)ix * ng + g] = c[(size_t)g * 64];
+  } else {
+    for (uint32_t g = 0; g < ng; g++) stream[(size_t)off + (size_t)g * 64 + lane] = c[(size_t)g * 64];
+  }
+}
 
 template <bool DOT>
 __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict__ hdrs,
-    const uint32_t* __restrict__ jcodes, const uint16_t* __restrict__ rowBase,
-    const PatEntry* __restrict__ classDict, const TileSeg* __restrict__ segs,
-    const double* __restrict__ x, double* __restrict__ y, uint32_t nr, uint32_t nChunks,
-    uint32_t blocksPerXcd, uint32_t padCol, double* __restrict__ dotPartials,
+    const uint32_t* __restrict__ stream, const uint16_t* __restrict__ rowBase,
+    const PatEntry* __restrict__ classDict, const PatEntry* __restrict__ rowPats,
+    const TileSeg* __restrict__ segs, const double* __restrict__ x, double* __restrict__ y, uint32_t nr,
+    uint32_t nChunks, uint32_t blocksPerXcd, uint32_t padCol, double* __restrict__ dotPartials,
     const int* __restrict__ stop)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[]; // [256 PatEntry][window]
   PatEntry* sd = reinterpret_cast<PatEntry*>(lds);
   double* sx   = lds + 512;
   constexpr int PF = 8; // code groups prefetched (32 columns); wider chunks stream the rest
-  constexpr int WB = 8; // window entries per thread and pass
+  constexpr int WB = 8; // window entries per thread in the first pass
   const uint32_t nTiles = (nChunks + 3u) >> 2;
   const uint32_t tile0  = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
   const uint32_t tile   = min(tile0, nTiles - 1u); // clamped: every load below is unconditional
-  // round trip 1: ONE vector load brings the tile header (lanes 0..31) and the stop flag
-  // (lane 32); fields are then read out of the lanes (v_readlane -> SGPRs)
+  // round trip 1: ONE vector load brings the tile header (lanes 0..47) and the stop flag
+  // (lane 48); fields are then read out of the lanes (v_readlane -> SGPRs)
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t* hp  = reinterpret_cast<const uint32_t*>(hdrs + tile);
-  const uint32_t hv   = *(lane < 32u ? hp + lane : reinterpret_cast<const uint32_t*>(stop));
-  uint32_t H[32];
+  const uint32_t hv   = *(lane < (uint32_t)PAT_STOP_LANE ? hp + lane : reinterpret_cast<const uint32_t*>(stop));
+  auto field = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)hv, i); };
+  uint32_t segCol[PAT_INLINE_SEGS], segFirst[PAT_INLINE_SEGS];
 #pragma unroll
-  for (int i = 0; i < 32; i++) H[i] = (uint32_t)__builtin_amdgcn_readlane((int)hv, i);
-  const int stopped    = __builtin_amdgcn_readlane((int)hv, 32);
+  for (int s = 0; s < (int)PAT_INLINE_SEGS; s++) segCol[s] = field(12 + 3 * s), segFirst[s] = field(12 + 3 * s + 1);
+  const int stopped    = (int)field(PAT_STOP_LANE);
   const uint32_t wv    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t chunk = tile * 4u + wv;
   const uint32_t row   = chunk * 64u + lane;
   const bool active    = chunk < nChunks; // wave-uniform; inactive waves still help staging
-  const uint32_t grp   = (uint32_t)__builtin_amdgcn_readlane((int)hv, 4 + (int)wv);
-  const uint32_t len   = (uint32_t)__builtin_amdgcn_readlane((int)hv, 8 + (int)wv);
-  const uint32_t ng    = (len + 3u) >> 2;
-  const uint32_t cls = H[0], nseg = H[1], segPtr = H[2], winInline = H[30];
+  const uint32_t off   = (uint32_t)__builtin_amdgcn_readlane((int)hv, 4 + (int)wv);
+  const uint32_t lenf  = (uint32_t)__builtin_amdgcn_readlane((int)hv, 8 + (int)wv);
+  const uint32_t len = lenf & ~PAT_UNIFORM, ng = (len + 3u) >> 2;
+  const bool uni     = (lenf & PAT_UNIFORM) != 0u; // wave-uniform
+  const uint32_t excLo = (uint32_t)__builtin_amdgcn_readlane((int)hv, 36 + 2 * (int)wv);
+  const uint32_t excHi = (uint32_t)__builtin_amdgcn_readlane((int)hv, 37 + 2 * (int)wv);
+  const uint32_t cls = field(0), nseg = field(1), segPtr = field(2), winInline = field(30);
   // round trip 2: code stream, row bases, own x entries, pattern table, x window -- all
-  // addresses clamped into valid memory so that nothing waits for a branch
-  const uint32_t* cstream = jcodes + (size_t)grp * 64 + lane;
-  const uint32_t gLast    = ng ? ng - 1u : 0u;
+  // addresses clamped into valid memory so that nothing waits for a branch.  In a U chunk
+  // only the exception lanes have codes (lane-major); the other lanes re-read word 0.
+  const bool isExc       = uni && ((lane < 32u ? excLo >> lane : excHi >> (lane - 32u)) & 1u) != 0u;
+  const uint32_t excIdx  = __builtin_amdgcn_mbcnt_hi(excHi, __builtin_amdgcn_mbcnt_lo(excLo, 0u));
+  const uint32_t gLast   = ng ? ng - 1u : 0u;
+  const uint32_t* cbase  = stream + (size_t)off + (uni ? (isExc ? (size_t)excIdx * ng : 0u) : (size_t)lane);
+  const uint32_t cstride = uni ? (isExc ? 1u : 0u) : 64u;
   uint32_t cw[PF];
 #pragma unroll
-  for (int gi = 0; gi < PF; gi++) cw[gi] = stream_load(cstream + (size_t)min((uint32_t)gi, gLast) * 64);
+  for (int gi = 0; gi < PF; gi++) cw[gi] = stream_load(cbase + (size_t)min((uint32_t)gi, gLast) * cstride);
   const int32_t base  = (int32_t)rowBase[active ? row : 0u];
   const double xrow   = DOT ? x[min(row, nr - 1u)] : 0.0;
   const PatEntry mine = classDict[(size_t)cls * 256 + threadIdx.x];
@@ -524,8 +607,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
     const uint32_t slot = min((uint32_t)k * 256u + threadIdx.x, winInline - 1u);
     uint32_t col        = padCol; // slot 0: what padding multiplies (src/matrix-SCS.c:151-155)
 #pragma unroll
-    for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++)
-      col = slot >= H[12 + 3 * s + 1] ? H[12 + 3 * s] + (slot - H[12 + 3 * s + 1]) : col;
+    for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++) col = slot >= segFirst[s] ? segCol[s] + (slot - segFirst[s]) : col;
     t[k] = x[col];
   }
   // keep every load above in front of the exit test (the compiler would sink them behind it)
@@ -542,8 +624,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
     const uint32_t slot = w0 + threadIdx.x;
     uint32_t col        = padCol;
 #pragma unroll
-    for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++)
-      col = slot >= H[12 + 3 * s + 1] ? H[12 + 3 * s] + (slot - H[12 + 3 * s + 1]) : col;
+    for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++) col = slot >= segFirst[s] ? segCol[s] + (slot - segFirst[s]) : col;
     if (slot < winInline) sx[slot] = x[col];
   }
   for (uint32_t s = PAT_INLINE_SEGS; s < nseg; s++) { // rare: tiles with many ranges
@@ -553,32 +634,68 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   sd[threadIdx.x] = mine;
   __syncthreads();
   if (!active) return;
-  // accumulate left to right; the 4 table reads and then the 4 x reads of a group are in
-  // flight together, columns past the chunk's width are computed but not added
   double acc = 0.0;
-  auto group = [&](uint32_t cwv, uint32_t j0) {
-    PatEntry e[4];
-    double xs[4];
+  if (uni) {
+    // dominant lanes: entries of the row pattern from scalar registers; exception lanes
+    // override them per lane from their own codes and the table in LDS
+    const PatEntry* rp = rowPats + (uint32_t)__builtin_amdgcn_readlane((int)hv, 32 + (int)wv);
+    auto ugroup = [&](uint32_t cwg, uint32_t j0) {
+      double v[4], xs[4];
+      int32_t sl[4];
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) e[k] = sd[(cwv >> (8u * k)) & 255u];
+      for (uint32_t q = 0; q < 4; q++) {
+        const PatEntry e = rp[min(j0 + q, len - 1u)]; // uniform address: s_load
+        v[q]             = e.v;
+        sl[q]            = (base & (int32_t)e.mask) + e.delta;
+      }
+      if (isExc) { // divergent: only the odd lanes touch the table in LDS
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) xs[k] = sx[(base & (int32_t)e[k].mask) + e[k].delta];
+        for (uint32_t q = 0; q < 4; q++) {
+          const PatEntry e = sd[(cwg >> (8u * q)) & 255u];
+          v[q]             = e.v;
+          sl[q]            = (base & (int32_t)e.mask) + e.delta;
+        }
+      }
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) {
-      const double prod = e[k].v * xs[k];
-      const double sum  = acc + prod;
-      acc               = (j0 + k < len) ? sum : acc; // wave-uniform select
-    }
-  };
+      for (uint32_t q = 0; q < 4; q++) xs[q] = sx[sl[q]];
 #pragma unroll
-  for (int gi = 0; gi < PF; gi++)
-    if ((uint32_t)gi < ng) group(cw[gi], (uint32_t)gi * 4u);
-  for (uint32_t g = PF; g < ng; g++) group(stream_load(cstream + (size_t)g * 64), g * 4u);
+      for (uint32_t q = 0; q < 4; q++) {
+        const double prod = v[q] * xs[q];
+        const double sum  = acc + prod;
+        acc               = (j0 + q < len) ? sum : acc; // wave-uniform select
+      }
+    };
+#pragma unroll
+    for (int gi = 0; gi < PF; gi++)
+      if ((uint32_t)gi < ng) ugroup(cw[gi], (uint32_t)gi * 4u);
+    for (uint32_t g = PF; g < ng; g++) ugroup(stream_load(cbase + (size_t)g * cstride), g * 4u);
+  } else {
+    // per-lane codes; the 4 table reads and then the 4 x reads of a group are in flight
+    // together, columns past the chunk's width are computed but not added
+    auto group = [&](uint32_t cwv, uint32_t j0) {
+      PatEntry e[4];
+      double xs[4];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) e[q] = sd[(cwv >> (8u * q)) & 255u];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) xs[q] = sx[(base & (int32_t)e[q].mask) + e[q].delta];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) {
+        const double prod = e[q].v * xs[q];
+        const double sum  = acc + prod;
+        acc               = (j0 + q < len) ? sum : acc; // wave-uniform select
+      }
+    };
+#pragma unroll
+    for (int gi = 0; gi < PF; gi++)
+      if ((uint32_t)gi < ng) group(cw[gi], (uint32_t)gi * 4u);
+    for (uint32_t g = PF; g < ng; g++) group(stream_load(cbase + (size_t)g * 64), g * 4u);
+  }
   if (row < nr) y[row] = acc;
   if (DOT) {
-    double t = row < nr ? xrow * acc : 0.0;
-    t        = butterfly64(t);
-    if (lane == 0) dotPartials[chunk] = t;
+    double t2 = row < nr ? xrow * acc : 0.0;
+    t2        = butterfly64(t2);
+    if (lane == 0) dotPartials[chunk] = t2;
   }
 }
 

@@ -20,6 +20,8 @@
 
 #include <algorithm>
 #include <iterator>
+#include <string>
+#include <unordered_map>
 
 using namespace sbk;
 
@@ -189,6 +191,8 @@ struct sb_matrix {
   uint32_t *tileClass = nullptr, *jcodes = nullptr;
   PatEntry* classDict   = nullptr;
   TileHdr* tileHdrs     = nullptr;
+  PatEntry* rowPats     = nullptr; // level 5: shared row patterns
+  uint32_t nRowPats = 0, nUniformChunks = 0;
   uint32_t nPatClasses  = 0;
   double patBytes       = 0.0;
 };
@@ -583,8 +587,9 @@ static void build_lds_windows(sb_matrix* m, const uint32_t* chunkPtr, const uint
   m->usePacked = 2; // 2: packed stream + x window in LDS
 }
 
-// Level 4: one byte per element naming a (value, slot delta) pair of the tile's class
-// (pack.hip.h).  Needs the value dictionary and the LDS windows.
+// Level 4: one byte per element naming a (value, slot delta) pair of the tile's class;
+// level 5: per chunk one shared row pattern + the odd lanes (pack.hip.h).  Needs the value
+// dictionary and the LDS windows.  SB_PACK=4 stops at level 4 (every chunk per-lane).
 static void build_patterns(sb_matrix* m)
 {
   if (m->usePacked != 2 || m->nDict <= 0) return;
@@ -652,14 +657,74 @@ static void build_patterns(sb_matrix* m)
   std::vector<PackMeta> meta(m->nChunks);
   sb_d2h(meta.data(), m->pmeta, meta.size() * sizeof(PackMeta));
   const uint64_t groups = (uint64_t)meta.back().grp + ((meta.back().info & 0x7FFFFFFFu) + 3u) / 4u;
-  HIP_CHECK(hipMalloc(&m->jcodes, (size_t)groups * 256 + 1024));
+  uint32_t* lanes = nullptr; // per-lane code words, group-major (the L form of every chunk)
+  HIP_CHECK(hipMalloc(&lanes, (size_t)groups * 256 + 1024));
   hipLaunchKernelGGL(pat_encode_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, m->pslots, m->pcodes,
-      m->nChunks, m->rowBase, m->tileClass, dClassKeys, m->jcodes);
+      m->nChunks, m->rowBase, m->tileClass, dClassKeys, lanes);
+  HIP_CHECK(hipGetLastError());
+  // Level 5 (row patterns): dominant code sequence and exception lanes of every chunk
+  const bool wantRows = (env ? atoi(env) : 5) >= 5;
+  uint32_t *dDom = nullptr, *dExc = nullptr;
+  HIP_CHECK(hipMalloc(&dDom, (size_t)groups * sizeof(uint32_t) + 16));
+  HIP_CHECK(hipMalloc(&dExc, (size_t)m->nChunks * 2 * sizeof(uint32_t)));
+  hipLaunchKernelGGL(pat_dominant_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dDom,
+      dExc);
+  HIP_CHECK(hipGetLastError());
+  std::vector<uint32_t> dom(groups ? groups : 1), exc((size_t)m->nChunks * 2);
+  sb_d2h(dom.data(), dDom, (size_t)groups * sizeof(uint32_t));
+  sb_d2h(exc.data(), dExc, exc.size() * sizeof(uint32_t));
+  HIP_CHECK(hipFree(dDom));
+  // chunk by chunk: U (row pattern + exception lanes) or L (all 64 lanes); row patterns are
+  // shared between chunks (key: the expanded entries)
+  const size_t maxPatEntries = 1u << 20; // 16 MiB of pattern rows at most
+  std::vector<PatEntry> rowPats;
+  std::unordered_map<std::string, uint32_t> patIndex;
+  std::vector<uint32_t> chunkOff(m->nChunks), chunkFlags(m->nChunks), chunkPat(m->nChunks, 0);
+  std::vector<PatEntry> row;
+  uint64_t words = 0;
+  m->nUniformChunks = 0;
+  for (uint32_t c = 0; c < m->nChunks; c++) {
+    const uint32_t len = meta[c].info & 0x7FFFFFFFu, ng = (len + 3u) / 4u;
+    const uint32_t nExc = (uint32_t)__builtin_popcount(exc[2 * (size_t)c]) +
+                          (uint32_t)__builtin_popcount(exc[2 * (size_t)c + 1]);
+    bool uni = wantRows && len > 0 && nExc <= PAT_EXC_MAX;
+    if (uni) {
+      row.resize(len);
+      const PatEntry* cd = classDict.data() + (size_t)tileClass[c / 4] * 256;
+      for (uint32_t j = 0; j < len; j++) row[j] = cd[(dom[meta[c].grp + j / 4] >> (8u * (j & 3u))) & 255u];
+      std::string key((const char*)row.data(), row.size() * sizeof(PatEntry));
+      auto it = patIndex.find(key);
+      if (it != patIndex.end()) chunkPat[c] = it->second;
+      else if (rowPats.size() + len <= maxPatEntries) {
+        chunkPat[c] = (uint32_t)rowPats.size();
+        patIndex.emplace(std::move(key), chunkPat[c]);
+        rowPats.insert(rowPats.end(), row.begin(), row.end());
+      } else uni = false; // table full
+    }
+    chunkOff[c]   = (uint32_t)words;
+    chunkFlags[c] = len | (uni ? PAT_UNIFORM : 0u);
+    words += uni ? (uint64_t)nExc * ng : (uint64_t)ng * 64u;
+    m->nUniformChunks += uni;
+  }
+  if (words > 0xFFFFFFFFull) {
+    sb_free(lanes), sb_free(dExc), sb_free(dClassKeys);
+    sb_free(m->classDict), m->classDict = nullptr;
+    return giveUp();
+  }
+  uint32_t* dOff   = (uint32_t*)upload(chunkOff.data(), chunkOff.size() * sizeof(uint32_t));
+  uint32_t* dFlags = (uint32_t*)upload(chunkFlags.data(), chunkFlags.size() * sizeof(uint32_t));
+  HIP_CHECK(hipMalloc(&m->jcodes, (size_t)words * sizeof(uint32_t) + 1024)); // slack: clamped reads past the end
+  HIP_CHECK(hipMemsetAsync(m->jcodes, 0, (size_t)words * sizeof(uint32_t) + 1024, g.stream));
+  hipLaunchKernelGGL(pat_compact_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dOff,
+      dFlags, dExc, m->jcodes);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(g.stream));
-  HIP_CHECK(hipFree(dClassKeys));
+  sb_free(lanes), sb_free(dExc), sb_free(dOff), sb_free(dFlags), sb_free(dClassKeys);
+  if (rowPats.empty()) rowPats.push_back(PatEntry{ 0.0, 0, 0u });
+  m->rowPats     = (PatEntry*)upload(rowPats.data(), rowPats.size() * sizeof(PatEntry));
+  m->nRowPats    = (uint32_t)patIndex.size();
   m->nPatClasses = (uint32_t)classes.size();
-  // one 128-byte header per tile: class, chunk positions / widths, the first segments
+  // one header per tile: class, chunk positions / widths / row patterns, the first segments
   std::vector<uint32_t> segPtr(nTiles + 1);
   sb_d2h(segPtr.data(), m->tileSegPtr, segPtr.size() * sizeof(uint32_t));
   const size_t nSegs = segPtr[nTiles];
@@ -672,7 +737,9 @@ static void build_patterns(sb_matrix* m)
     h.cls = tileClass[t], h.nseg = segPtr[t + 1] - segPtr[t], h.segPtr = segPtr[t], h.win = 1;
     for (uint32_t w = 0; w < 4; w++) {
       const uint32_t c = t * 4 + w;
-      if (c < m->nChunks) h.grp[w] = meta[c].grp, h.len[w] = meta[c].info & 0x7FFFFFFFu;
+      if (c >= m->nChunks) continue;
+      h.off[w] = chunkOff[c], h.len[w] = chunkFlags[c], h.rowPat[w] = chunkPat[c];
+      if (chunkFlags[c] & PAT_UNIFORM) h.exc[w][0] = exc[2 * (size_t)c], h.exc[w][1] = exc[2 * (size_t)c + 1];
     }
     for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++) h.seg[s][1] = 0xFFFFFFFFu;
     h.winInline = 1;
@@ -686,9 +753,9 @@ static void build_patterns(sb_matrix* m)
     }
   }
   m->tileHdrs = (TileHdr*)upload(hdrs.data(), hdrs.size() * sizeof(TileHdr));
-  m->patBytes  = (double)groups * 256.0 + 2.0 * 64.0 * m->nChunks + 16.0 * m->nChunks + 16.0 * nSegs +
-                 128.0 * nTiles + 4096.0 * classes.size();
-  m->usePacked = 3; // 3: pattern codes + x window in LDS
+  m->patBytes = (double)words * 4.0 + 2.0 * 64.0 * m->nChunks + 16.0 * nSegs + (double)sizeof(TileHdr) * nTiles +
+                4096.0 * classes.size() + 16.0 * rowPats.size();
+  m->usePacked = 3; // 3: pattern codes / row patterns + x window in LDS
 }
 
 sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, uint32_t nChunks,
@@ -748,7 +815,7 @@ void sb_matrix_free(sb_matrix* m)
   sb_free(m->oldToNew), sb_free(m->newToOld), sb_free(m->colInd), sb_free(m->val);
   sb_free(m->pmeta), sb_free(m->pidx), sb_free(m->pcodes), sb_free(m->pdict);
   sb_free(m->tileSegPtr), sb_free(m->tileSegs), sb_free(m->pslots);
-  sb_free(m->rowBase), sb_free(m->tileClass), sb_free(m->jcodes), sb_free(m->classDict), sb_free(m->tileHdrs);
+  sb_free(m->rowBase), sb_free(m->tileClass), sb_free(m->jcodes), sb_free(m->classDict), sb_free(m->tileHdrs), sb_free(m->rowPats);
   delete m;
 }
 
@@ -764,6 +831,11 @@ void sb_matrix_use_packed(sb_matrix* m, int mode)
 int sb_matrix_packed_mode(const sb_matrix* m) { return m->usePacked; }
 uint32_t sb_matrix_lds_window(const sb_matrix* m) { return m->ldsWindow; }
 uint32_t sb_matrix_pattern_classes(const sb_matrix* m) { return m->nPatClasses; }
+uint32_t sb_matrix_row_patterns(const sb_matrix* m, uint32_t* uniformChunks)
+{
+  if (uniformChunks) *uniformChunks = m->nUniformChunks;
+  return m->nRowPats;
+}
 double sb_matrix_stream_bytes(const sb_matrix* m)
 { // bytes the SELECTED SpMV kernel moves per launch (matrix stream + x once + y once)
   if (m->fmt == 1 && m->usePacked == 3) return m->patBytes + 8.0 * m->nrPadded + 8.0 * m->nc;
@@ -816,10 +888,12 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
       if (!stop) stop = zero_flag();
       if (dot)
         hipLaunchKernelGGL((spmv_scs64_pat<true>), grid, block, shmem, g.stream, m->tileHdrs, m->jcodes,
-            m->rowBase, m->classDict, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol, dotPartials, stop);
+            m->rowBase, m->classDict, m->rowPats, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol,
+            dotPartials, stop);
       else
         hipLaunchKernelGGL((spmv_scs64_pat<false>), grid, block, shmem, g.stream, m->tileHdrs, m->jcodes,
-            m->rowBase, m->classDict, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol, dotPartials, stop);
+            m->rowBase, m->classDict, m->rowPats, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol,
+            dotPartials, stop);
     } else if (m->usePacked == 2) {
       const size_t shmem = (256 + (size_t)m->ldsWindow) * sizeof(double);
 #define LDS_LAUNCH(DI, DO)                                                                                   \

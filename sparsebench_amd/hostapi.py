@@ -144,7 +144,10 @@ class Problem:
 
     def pack_info(self):
         L = capi.load()
+        uni = C.c_uint32(0)
+        pats = L.sb_matrix_row_patterns(self.matrix, C.byref(uni))
         return {"level": L.sb_matrix_pack_level(self.matrix), "mode": L.sb_matrix_packed_mode(self.matrix),
+                "row_patterns": pats, "uniform_chunks": uni.value,
                 "lds_window_doubles": L.sb_matrix_lds_window(self.matrix),
                 "pattern_classes": L.sb_matrix_pattern_classes(self.matrix)}
 

@@ -183,27 +183,40 @@ def test_pattern_dictionary_mode(gpu, monkeypatch):
     rng = np.random.default_rng(29)
     # sigma > 1 on SMALL grids scatters a tile's rows over many lines: > 255 pairs per tile, the
     # matrix then stays at mode 2 (allowed); with 128-row lines (the headline shape) mode 3 is built
-    for dims, sg, must in (((16, 16, 16), 1, True), ((16, 16, 16), 256, False), ((9, 8, 7), 64, False),
-                           ((20, 5, 33), 4096, False), ((128, 128, 2), 256, True), ((70, 3, 5), 1, True)):
-        g = po.GMatrix.generate(*dims)
-        s = g.to_scs(64, sg)
-        m = upload_scs(L, s)
-        assert L.sb_matrix_lds_window(m) > 0
-        if must:
-            assert L.sb_matrix_pattern_classes(m) >= 1 and L.sb_matrix_packed_mode(m) == 3, (dims, sg)
-            L.sb_matrix_use_packed(m, 2)
-            lds_bytes = L.sb_matrix_stream_bytes(m)
-            L.sb_matrix_use_packed(m, 3)
-            assert L.sb_matrix_stream_bytes(m) < 0.62 * lds_bytes
-        x = rng.standard_normal(g.nc)
-        assert np.array_equal(gpu_spmv(L, m, x, g.nr), g.spmv(x))
-        # NaN / Inf in x reach exactly the rows the reference lets them reach (padding -> x[padCol])
-        x[0], x[g.nc // 2] = np.inf, np.nan
-        got, exp = gpu_spmv(L, m, x, g.nr), s.spmv(x)
-        assert np.isnan(exp).any() and np.array_equal(np.isnan(got), np.isnan(exp))
-        ok = ~np.isnan(exp)
-        assert np.array_equal(got[ok].view(np.uint64), exp[ok].view(np.uint64))
-        L.sb_matrix_free(m)
+    cases = (((16, 16, 16), 1, True), ((16, 16, 16), 256, False), ((9, 8, 7), 64, False),
+             ((20, 5, 33), 4096, False), ((128, 128, 2), 256, True), ((70, 3, 5), 1, True))
+    for pack in (None, "4"):  # default: row patterns (level 5) where they pay; SB_PACK=4: per-lane codes only
+        if pack:
+            monkeypatch.setenv("SB_PACK", pack)
+        for dims, sg, must in cases:
+            g = po.GMatrix.generate(*dims)
+            s = g.to_scs(64, sg)
+            m = upload_scs(L, s)
+            assert L.sb_matrix_lds_window(m) > 0
+            uni = C.c_uint32(0)
+            pats = L.sb_matrix_row_patterns(m, C.byref(uni))
+            if must:
+                assert L.sb_matrix_pattern_classes(m) >= 1 and L.sb_matrix_packed_mode(m) == 3, (dims, sg)
+                L.sb_matrix_use_packed(m, 2)
+                lds_bytes = L.sb_matrix_stream_bytes(m)
+                L.sb_matrix_use_packed(m, 3)
+                assert L.sb_matrix_stream_bytes(m) < 0.62 * lds_bytes
+                if pack is None:  # most chunks are one shared row pattern + a few odd lanes
+                    assert pats >= 1 and uni.value >= 0.7 * s.nChunks, (dims, sg, pats, uni.value, s.nChunks)
+                    assert L.sb_matrix_stream_bytes(m) < 0.45 * lds_bytes
+            if pack:
+                assert pats == 0 and uni.value == 0
+            x = rng.standard_normal(g.nc)
+            assert np.array_equal(gpu_spmv(L, m, x, g.nr), g.spmv(x))
+            # NaN / Inf in x reach exactly the rows the reference lets them reach (padding -> x[padCol])
+            x[0], x[g.nc // 2] = np.inf, np.nan
+            got, exp = gpu_spmv(L, m, x, g.nr), s.spmv(x)
+            assert np.isnan(exp).any() and np.array_equal(np.isnan(got), np.isnan(exp))
+            ok = ~np.isnan(exp)
+            assert np.array_equal(got[ok].view(np.uint64), exp[ok].view(np.uint64))
+            L.sb_matrix_free(m)
+        if pack:
+            monkeypatch.delenv("SB_PACK")
     # banded matrix, 200 distinct values used round-robin: the LDS window is built (forced),
     # but a tile holds far more than 255 (value, delta) pairs -> stays at mode 2
     monkeypatch.setenv("SB_PACK_LDS", "1")
