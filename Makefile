@@ -10,7 +10,7 @@ all: hip host oracle
 
 hip: $(LIBDIR)/libsbhip.so
 
-$(LIBDIR)/libsbhip.so: $(CSRC)/sbhip.hip $(CSRC)/kernels.hip.h include/sbhip.h
+$(LIBDIR)/libsbhip.so: $(CSRC)/sbhip.hip $(wildcard $(CSRC)/*.h) include/sbhip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/sbhip.hip -ldl
 

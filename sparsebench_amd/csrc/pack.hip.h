@@ -346,14 +346,14 @@ __global__ __launch_bounds__(256) void spmv_scs64_lds(const PackMeta* __restrict
 // merges tiles into classes of <= 255 pairs (a 27-point stencil on one GPU: one or a
 // handful of classes); a workgroup stages its class's table (4 KiB: value, delta, mask)
 // next to the x window and per element does
-//        e = table[code];   acc = acc + e.v * sx[(rowBase & e.mask) + e.delta]
+//        e = table[code];   acc = acc + e.v * window[8 * rowBase * e.m + e.off8]   (byte offset)
 // rowBase is a 16-bit slot per row; padding keeps its reference meaning through
-// mask = 0, delta = 0 (slot 0 = x[padCol]).  1 B per element instead of 3, still lossless,
+// m = 0, off8 = 0 (slot 0 = x[padCol]).  1 B per element instead of 3, still lossless,
 // same order, same bits.  Any tile with > 255 pairs: the matrix stays at level 3.
 struct PatEntry {
   double v;
-  int32_t delta;
-  uint32_t mask;
+  uint32_t off8; // byte offset of the element's x in the window, relative to 8 * rowBase * m
+  uint32_t m;    // 1; 0 for padding (then off8 = 0: slot 0)
 };
 
 constexpr uint32_t PAT_ABS   = 0x01000000u; // key bit: absolute slot 0 (padding)
@@ -472,6 +472,7 @@ __global__ __launch_bounds__(256) void pat_encode_k(const PackMeta* __restrict__
 // is full, stay in the per-lane form (L chunks).  Lossless, same order, same bits.
 constexpr uint32_t PAT_INLINE_SEGS = 6;
 constexpr uint32_t PAT_UNIFORM     = 0x80000000u; // TileHdr.len[] flag: dominant-pattern chunk
+constexpr uint32_t PAT_NOPAD       = 0x40000000u; // ... whose dominant pattern holds no padding
 constexpr uint32_t PAT_EXC_MAX     = 24;          // more exception lanes than this: L chunk
 
 // Everything a workgroup needs to know about its tile, in one 192-byte record: the kernel is
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   const bool active    = chunk < nChunks; // wave-uniform; inactive waves still help staging
   const uint32_t off   = (uint32_t)__builtin_amdgcn_readlane((int)hv, 4 + (int)wv);
   const uint32_t lenf  = (uint32_t)__builtin_amdgcn_readlane((int)hv, 8 + (int)wv);
-  const uint32_t len = lenf & ~PAT_UNIFORM, ng = (len + 3u) >> 2;
+  const uint32_t len = lenf & ~(PAT_UNIFORM | PAT_NOPAD), ng = (len + 3u) >> 2;
   const bool uni     = (lenf & PAT_UNIFORM) != 0u; // wave-uniform
   const uint32_t excLo = (uint32_t)__builtin_amdgcn_readlane((int)hv, 36 + 2 * (int)wv);
   const uint32_t excHi = (uint32_t)__builtin_amdgcn_readlane((int)hv, 37 + 2 * (int)wv);
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   // keep every load above in front of the exit test (the compiler would sink them behind it)
   asm volatile("" ::"v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]));
   asm volatile("" ::"v"(cw[0]), "v"(cw[1]), "v"(cw[2]), "v"(cw[3]), "v"(cw[4]), "v"(cw[5]), "v"(cw[6]),
-               "v"(cw[7]), "v"(base), "v"(xrow), "v"(mine.v), "v"(mine.delta), "v"(mine.mask));
+               "v"(cw[7]), "v"(base), "v"(xrow), "v"(mine.v), "v"(mine.off8), "v"(mine.m));
   if (tile0 >= nTiles || stopped) return; // uniform per workgroup
 #pragma unroll
   for (int k = 0; k < WB; k++) {
@@ -634,62 +635,91 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   sd[threadIdx.x] = mine;
   __syncthreads();
   if (!active) return;
-  double acc = 0.0;
+  // An element costs: table entry -> byte offset of its x in the window (one multiply-add:
+  // base8 * m + off8, m = 0 for padding) -> x -> multiply -> add.  The kernel is bound by
+  // VALU issue and LDS as much as by latency, so the per-element instruction count matters:
+  // offsets are pre-scaled, and only a chunk's last, partial group pays for the
+  // "column < width" selects.
+  double acc           = 0.0;
+  const uint32_t base8 = (uint32_t)base << 3;
+  auto xread = [&](uint32_t off) -> double {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(sx) + off);
+  };
   if (uni) {
     // dominant lanes: entries of the row pattern from scalar registers; exception lanes
-    // override them per lane from their own codes and the table in LDS
+    // override them per lane from their own codes and the table in LDS.  Two groups
+    // (8 columns) at a time: 8 entry loads, then the odd lanes' 8 table reads, then 8 x reads
+    // are in flight together.
     const PatEntry* rp = rowPats + (uint32_t)__builtin_amdgcn_readlane((int)hv, 32 + (int)wv);
-    auto ugroup = [&](uint32_t cwg, uint32_t j0) {
-      double v[4], xs[4];
-      int32_t sl[4];
+    const bool nopad   = (lenf & PAT_NOPAD) != 0u; // wave-uniform: no padding in the dominant pattern
+    auto upair = [&](uint32_t cwa, uint32_t cwb, uint32_t j0, const bool full, const bool np) {
+      double v[8], xs[8];
+      uint32_t off[8];
 #pragma unroll
-      for (uint32_t q = 0; q < 4; q++) {
-        const PatEntry e = rp[min(j0 + q, len - 1u)]; // uniform address: s_load
-        v[q]             = e.v;
-        sl[q]            = (base & (int32_t)e.mask) + e.delta;
+      for (uint32_t q = 0; q < 8; q++) {
+        const PatEntry e = rp[full ? j0 + q : min(j0 + q, len - 1u)]; // uniform address: s_load
+        // (pinned to scalar registers: otherwise the compiler merges this load with the odd
+        //  lanes' LDS read below into ONE flat load through a selected generic pointer)
+        const unsigned long long vb = __builtin_bit_cast(unsigned long long, e.v);
+        const unsigned long long vs =
+            (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vb) |
+            ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(vb >> 32)) << 32);
+        v[q]   = __builtin_bit_cast(double, vs);
+        off[q] = np ? base8 + e.off8 : __umul24(base8, e.m) + e.off8;
       }
       if (isExc) { // divergent: only the odd lanes touch the table in LDS
 #pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {
-          const PatEntry e = sd[(cwg >> (8u * q)) & 255u];
+        for (uint32_t q = 0; q < 8; q++) {
+          const PatEntry e = sd[((q < 4 ? cwa : cwb) >> (8u * (q & 3u))) & 255u];
           v[q]             = e.v;
-          sl[q]            = (base & (int32_t)e.mask) + e.delta;
+          off[q]           = __umul24(base8, e.m) + e.off8;
         }
       }
 #pragma unroll
-      for (uint32_t q = 0; q < 4; q++) xs[q] = sx[sl[q]];
+      for (uint32_t q = 0; q < 8; q++) xs[q] = xread(off[q]);
 #pragma unroll
-      for (uint32_t q = 0; q < 4; q++) {
+      for (uint32_t q = 0; q < 8; q++) {
         const double prod = v[q] * xs[q];
         const double sum  = acc + prod;
-        acc               = (j0 + q < len) ? sum : acc; // wave-uniform select
+        acc               = (full || j0 + q < len) ? sum : acc; // wave-uniform select
       }
     };
+    auto upick = [&](uint32_t cwa, uint32_t cwb, uint32_t j0) {
+      if (j0 + 8u <= len) {
+        if (nopad) upair(cwa, cwb, j0, true, true);
+        else upair(cwa, cwb, j0, true, false);
+      } else upair(cwa, cwb, j0, false, false);
+    };
 #pragma unroll
-    for (int gi = 0; gi < PF; gi++)
-      if ((uint32_t)gi < ng) ugroup(cw[gi], (uint32_t)gi * 4u);
-    for (uint32_t g = PF; g < ng; g++) ugroup(stream_load(cbase + (size_t)g * cstride), g * 4u);
+    for (int gi = 0; gi < PF; gi += 2)
+      if ((uint32_t)gi < ng) upick(cw[gi], cw[gi + 1], (uint32_t)gi * 4u);
+    for (uint32_t g = PF; g < ng; g += 2)
+      upick(stream_load(cbase + (size_t)g * cstride), stream_load(cbase + (size_t)min(g + 1u, gLast) * cstride), g * 4u);
   } else {
     // per-lane codes; the 4 table reads and then the 4 x reads of a group are in flight
     // together, columns past the chunk's width are computed but not added
-    auto group = [&](uint32_t cwv, uint32_t j0) {
+    auto group = [&](uint32_t cwv, uint32_t j0, const bool full) {
       PatEntry e[4];
       double xs[4];
 #pragma unroll
       for (uint32_t q = 0; q < 4; q++) e[q] = sd[(cwv >> (8u * q)) & 255u];
 #pragma unroll
-      for (uint32_t q = 0; q < 4; q++) xs[q] = sx[(base & (int32_t)e[q].mask) + e[q].delta];
+      for (uint32_t q = 0; q < 4; q++) xs[q] = xread(__umul24(base8, e[q].m) + e[q].off8);
 #pragma unroll
       for (uint32_t q = 0; q < 4; q++) {
         const double prod = e[q].v * xs[q];
         const double sum  = acc + prod;
-        acc               = (j0 + q < len) ? sum : acc; // wave-uniform select
+        acc               = (full || j0 + q < len) ? sum : acc; // wave-uniform select
       }
+    };
+    auto pick = [&](uint32_t cwv, uint32_t j0) {
+      if (j0 + 4u <= len) group(cwv, j0, true);
+      else group(cwv, j0, false);
     };
 #pragma unroll
     for (int gi = 0; gi < PF; gi++)
-      if ((uint32_t)gi < ng) group(cw[gi], (uint32_t)gi * 4u);
-    for (uint32_t g = PF; g < ng; g++) group(stream_load(cbase + (size_t)g * 64), g * 4u);
+      if ((uint32_t)gi < ng) pick(cw[gi], (uint32_t)gi * 4u);
+    for (uint32_t g = PF; g < ng; g++) pick(stream_load(cbase + (size_t)g * 64), g * 4u);
   }
   if (row < nr) y[row] = acc;
   if (DOT) {

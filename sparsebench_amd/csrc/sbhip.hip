@@ -648,8 +648,8 @@ static void build_patterns(sb_matrix* m)
       classKeys[c * 256 + i]   = key;
       PatEntry& e              = classDict[c * 256 + i];
       e.v                      = dict[key & 255u];
-      if (key & PAT_ABS) e.delta = 0, e.mask = 0u;
-      else e.delta = (int32_t)((key >> 8) & 0xFFFFu) - 32768, e.mask = 0xFFFFFFFFu;
+      if (key & PAT_ABS) e.off8 = 0u, e.m = 0u; // padding: slot 0
+      else e.off8 = (uint32_t)(8 * ((int32_t)((key >> 8) & 0xFFFFu) - 32768)), e.m = 1u; // 8 * (slot - rowBase), mod 2^32
     }
   uint32_t* dClassKeys = (uint32_t*)upload(classKeys.data(), classKeys.size() * sizeof(uint32_t));
   m->tileClass         = (uint32_t*)upload(tileClass.data(), tileClass.size() * sizeof(uint32_t));
@@ -657,6 +657,12 @@ static void build_patterns(sb_matrix* m)
   std::vector<PackMeta> meta(m->nChunks);
   sb_d2h(meta.data(), m->pmeta, meta.size() * sizeof(PackMeta));
   const uint64_t groups = (uint64_t)meta.back().grp + ((meta.back().info & 0x7FFFFFFFu) + 3u) / 4u;
+  for (const PackMeta& pm : meta)
+    if ((pm.info & 0x7FFFFFFFu) >= PAT_NOPAD) { // chunk width collides with the header's flag bits
+      sb_free(dClassKeys), sb_free(m->tileClass), sb_free(m->classDict);
+      m->tileClass = nullptr, m->classDict = nullptr;
+      return giveUp();
+    }
   uint32_t* lanes = nullptr; // per-lane code words, group-major (the L form of every chunk)
   HIP_CHECK(hipMalloc(&lanes, (size_t)groups * 256 + 1024));
   hipLaunchKernelGGL(pat_encode_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, m->pslots, m->pcodes,
@@ -687,11 +693,16 @@ static void build_patterns(sb_matrix* m)
     const uint32_t len = meta[c].info & 0x7FFFFFFFu, ng = (len + 3u) / 4u;
     const uint32_t nExc = (uint32_t)__builtin_popcount(exc[2 * (size_t)c]) +
                           (uint32_t)__builtin_popcount(exc[2 * (size_t)c + 1]);
-    bool uni = wantRows && len > 0 && nExc <= PAT_EXC_MAX;
+    bool uni = wantRows && len > 0 && nExc <= PAT_EXC_MAX, chunkNoPad = false;
     if (uni) {
       row.resize(len);
       const PatEntry* cd = classDict.data() + (size_t)tileClass[c / 4] * 256;
-      for (uint32_t j = 0; j < len; j++) row[j] = cd[(dom[meta[c].grp + j / 4] >> (8u * (j & 3u))) & 255u];
+      bool nopad = true;
+      for (uint32_t j = 0; j < len; j++) {
+        row[j] = cd[(dom[meta[c].grp + j / 4] >> (8u * (j & 3u))) & 255u];
+        nopad  = nopad && row[j].m == 1u;
+      }
+      chunkNoPad = nopad;
       std::string key((const char*)row.data(), row.size() * sizeof(PatEntry));
       auto it = patIndex.find(key);
       if (it != patIndex.end()) chunkPat[c] = it->second;
@@ -702,7 +713,7 @@ static void build_patterns(sb_matrix* m)
       } else uni = false; // table full
     }
     chunkOff[c]   = (uint32_t)words;
-    chunkFlags[c] = len | (uni ? PAT_UNIFORM : 0u);
+    chunkFlags[c] = len | (uni ? PAT_UNIFORM | (chunkNoPad ? PAT_NOPAD : 0u) : 0u);
     words += uni ? (uint64_t)nExc * ng : (uint64_t)ng * 64u;
     m->nUniformChunks += uni;
   }
