@@ -473,28 +473,34 @@ __global__ __launch_bounds__(256) void pat_encode_k(const PackMeta* __restrict__
 constexpr uint32_t PAT_INLINE_SEGS = 6;
 constexpr uint32_t PAT_UNIFORM     = 0x80000000u; // TileHdr.len[] flag: dominant-pattern chunk
 constexpr uint32_t PAT_NOPAD       = 0x40000000u; // ... whose dominant pattern holds no padding
-constexpr uint32_t PAT_EXC_MAX     = 24;          // more exception lanes than this: L chunk
+constexpr uint32_t PAT_EXC_MAX     = 8; // more exception lanes than this: L chunk (an exception
+                                        // row costs 16 B per column, a per-lane row 1 B)
 
-// Everything a workgroup needs to know about its tile, in one 192-byte record: the kernel is
-// latency-bound (a CU runs its tiles in 4 rounds and each round pays every DEPENDENT memory
-// round trip once), so header -> {codes, row bases, pattern table, x window} is the whole
-// chain: two round trips, everything else in parallel.
+// Everything a workgroup needs to know about its tile, in one 192-byte record: each round of
+// tiles a CU runs pays every DEPENDENT memory round trip once, so header -> {codes, row
+// bases, tables, x window} is the whole chain: two round trips, everything else in parallel.
 struct TileHdr {
   uint32_t cls;       // pattern class
   uint32_t nseg;      // segments of the window
   uint32_t segPtr;    // first segment in the global list (tiles with > PAT_INLINE_SEGS)
   uint32_t win;       // window entries incl. slot 0
-  uint32_t off[4];    // code-stream position (words) of the tile's chunks
-  uint32_t len[4];    // chunk widths (0 for chunks past the end) | PAT_UNIFORM
+  uint32_t off[4];    // L chunk: code-stream position (words); U chunk: first exception entry
+  uint32_t len[4];    // chunk widths (0 for chunks past the end) | PAT_UNIFORM | PAT_NOPAD
   uint32_t seg[PAT_INLINE_SEGS][3]; // first column, first slot (0xFFFFFFFF: unused), entries
   uint32_t winInline; // window entries covered by the inline segments
-  uint32_t pad_;
+  uint32_t flags;     // PAT_SIMPLE_WINDOW
   uint32_t rowPat[4]; // U chunks: first entry of the dominant row pattern
   uint32_t exc[4][2]; // U chunks: exception lanes (lo, hi)
-  uint32_t pad2_[4];
+  uint32_t excStart;  // the tile's exception entries: first, count (contiguous over its U chunks)
+  uint32_t excCount;
+  uint32_t pad_[2];
 };
 static_assert(sizeof(TileHdr) == 192, "TileHdr is 48 words");
-constexpr int PAT_STOP_LANE = 48; // the lane that fetches the stop flag next to the header
+constexpr int PAT_STOP_LANE          = 48; // the lane that fetches the stop flag next to the header
+// <= 6 segments, listed longest first: three of <= 768 entries (3 loads per thread) and three
+// of <= 256 (1 load): staged segment by segment, no per-entry search
+constexpr uint32_t PAT_SIMPLE_WINDOW = 1u;
+constexpr uint32_t PAT_EXC_LDS_MAX   = 1024; // exception entries per tile (16 KiB of LDS) at most
 
 // dominant code sequence of every chunk (majority of the 64 lanes) and the lanes that differ
 __global__ __launch_bounds__(256) void pat_dominant_k(const PackMeta* __restrict__ meta,
@@ -526,44 +532,60 @@ __global__ __launch_bounds__(256) void pat_dominant_k(const PackMeta* __restrict
   if (lane == 0) excMask[2 * (size_t)chunk] = (uint32_t)exc, excMask[2 * (size_t)chunk + 1] = (uint32_t)(exc >> 32);
 }
 
-// per-lane code words -> final stream: L chunks keep all 64 lanes (group-major), U chunks
-// only their exception lanes (lane-major: an exception lane's words are contiguous)
+// per-lane code words -> final form: L chunks keep the code words of all 64 lanes
+// (group-major); U chunks keep only their exception lanes, EXPANDED to (value, byte offset of
+// x in the window) entries, `len` per lane, lane after lane
 __global__ __launch_bounds__(256) void pat_compact_k(const PackMeta* __restrict__ meta,
     const uint32_t* __restrict__ jcodes, uint32_t nChunks, const uint32_t* __restrict__ chunkOff,
     const uint32_t* __restrict__ chunkFlags, const uint32_t* __restrict__ excMask,
-    uint32_t* __restrict__ stream)
+    const uint16_t* __restrict__ rowBase, const uint32_t* __restrict__ tileClass,
+    const PatEntry* __restrict__ classDict, uint32_t* __restrict__ stream, PatEntry* __restrict__ excRows)
 {
   const uint32_t chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
   const uint32_t lane  = threadIdx.x & 63u;
   if (chunk >= nChunks) return;
   const PackMeta m   = meta[chunk];
-  const uint32_t ng  = ((m.info & 0x7FFFFFFFu) + 3u) >> 2;
+  const uint32_t len = m.info & 0x7FFFFFFFu, ng = (len + 3u) >> 2;
   const uint32_t* c  = jcodes + (size_t)m.grp * 64 + lane;
   const uint32_t off = chunkOff[chunk];
   if (chunkFlags[chunk] & PAT_UNIFORM) {
     const uint32_t lo = excMask[2 * (size_t)chunk], hi = excMask[2 * (size_t)chunk + 1];
     const bool isExc  = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
     const uint32_t ix = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-    if (isExc)
-      for (uint32_t g = 0; g < ng; g++) stream[(size_t)off + (size_t)ix * ng + g] = c[(size_t)g * 64];
+    if (isExc) {
+      const PatEntry* cd   = classDict + (size_t)tileClass[blockIdx.x] * 256;
+      const uint32_t base8 = (uint32_t)rowBase[(size_t)chunk * 64 + lane] << 3;
+      for (uint32_t j = 0; j < len; j++) {
+        const PatEntry e = cd[(c[(size_t)(j >> 2) * 64] >> (8u * (j & 3u))) & 255u];
+        excRows[(size_t)off + (size_t)ix * len + j] = PatEntry{ e.v, base8 * e.m + e.off8, 0u };
+      }
+    }
   } else {
     for (uint32_t g = 0; g < ng; g++) stream[(size_t)off + (size_t)g * 64 + lane] = c[(size_t)g * 64];
   }
 }
 
+// Measured (rocprofv3 SQ counters, 128^3): with the stream down to ~40 MB the kernel is bound
+// by VALU ISSUE -- 503 vector instructions per wave against ~85 useful ones (address, multiply,
+// add per element).  So everything that is not the accumulate loop is kept out of the vector
+// ALU: the header is decoded with scalar ops, the window is copied segment by segment (no
+// per-entry search), U chunks read no code stream, and their odd lanes get ready-made
+// (value, offset) entries from LDS instead of decoding codes.
 template <bool DOT>
 __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict__ hdrs,
     const uint32_t* __restrict__ stream, const uint16_t* __restrict__ rowBase,
     const PatEntry* __restrict__ classDict, const PatEntry* __restrict__ rowPats,
-    const TileSeg* __restrict__ segs, const double* __restrict__ x, double* __restrict__ y, uint32_t nr,
-    uint32_t nChunks, uint32_t blocksPerXcd, uint32_t padCol, double* __restrict__ dotPartials,
-    const int* __restrict__ stop)
+    const PatEntry* __restrict__ excRows, const TileSeg* __restrict__ segs,
+    const double* __restrict__ x, double* __restrict__ y, uint32_t nr, uint32_t nChunks,
+    uint32_t blocksPerXcd, uint32_t padCol, uint32_t dictEntries, uint32_t excLds,
+    double* __restrict__ dotPartials, const int* __restrict__ stop)
 {
-  extern __shared__ __attribute__((aligned(16))) double lds[]; // [256 PatEntry][window]
+  extern __shared__ __attribute__((aligned(16))) double lds[]; // [dict][exception entries + 8][window]
   PatEntry* sd = reinterpret_cast<PatEntry*>(lds);
-  double* sx   = lds + 512;
+  PatEntry* se = sd + dictEntries;
+  double* sx   = reinterpret_cast<double*>(se + excLds + 8u);
   constexpr int PF = 8; // code groups prefetched (32 columns); wider chunks stream the rest
-  constexpr int WB = 8; // window entries per thread in the first pass
+  constexpr int WB = 12; // window entries per thread in the first pass
   const uint32_t nTiles = (nChunks + 3u) >> 2;
   const uint32_t tile0  = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
   const uint32_t tile   = min(tile0, nTiles - 1u); // clamped: every load below is unconditional
@@ -573,9 +595,6 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   const uint32_t* hp  = reinterpret_cast<const uint32_t*>(hdrs + tile);
   const uint32_t hv   = *(lane < (uint32_t)PAT_STOP_LANE ? hp + lane : reinterpret_cast<const uint32_t*>(stop));
   auto field = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)hv, i); };
-  uint32_t segCol[PAT_INLINE_SEGS], segFirst[PAT_INLINE_SEGS];
-#pragma unroll
-  for (int s = 0; s < (int)PAT_INLINE_SEGS; s++) segCol[s] = field(12 + 3 * s), segFirst[s] = field(12 + 3 * s + 1);
   const int stopped    = (int)field(PAT_STOP_LANE);
   const uint32_t wv    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t chunk = tile * 4u + wv;
@@ -587,74 +606,124 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   const bool uni     = (lenf & PAT_UNIFORM) != 0u; // wave-uniform
   const uint32_t excLo = (uint32_t)__builtin_amdgcn_readlane((int)hv, 36 + 2 * (int)wv);
   const uint32_t excHi = (uint32_t)__builtin_amdgcn_readlane((int)hv, 37 + 2 * (int)wv);
-  const uint32_t cls = field(0), nseg = field(1), segPtr = field(2), winInline = field(30);
-  // round trip 2: code stream, row bases, own x entries, pattern table, x window -- all
-  // addresses clamped into valid memory so that nothing waits for a branch.  In a U chunk
-  // only the exception lanes have codes (lane-major); the other lanes re-read word 0.
-  const bool isExc       = uni && ((lane < 32u ? excLo >> lane : excHi >> (lane - 32u)) & 1u) != 0u;
-  const uint32_t excIdx  = __builtin_amdgcn_mbcnt_hi(excHi, __builtin_amdgcn_mbcnt_lo(excLo, 0u));
-  const uint32_t gLast   = ng ? ng - 1u : 0u;
-  const uint32_t* cbase  = stream + (size_t)off + (uni ? (isExc ? (size_t)excIdx * ng : 0u) : (size_t)lane);
-  const uint32_t cstride = uni ? (isExc ? 1u : 0u) : 64u;
+  const uint32_t cls = field(0), nseg = field(1), winInline = field(30), flags = field(31);
+  const uint32_t excStart = field(44), excCount = field(45);
+  const bool simple = (flags & PAT_SIMPLE_WINDOW) != 0u; // uniform per workgroup
+  // round trip 2: codes (L chunks), row bases, own x entries, tables, x window -- addresses
+  // clamped into valid memory so that nothing waits for a branch
+  const bool isExc      = uni && ((lane < 32u ? excLo >> lane : excHi >> (lane - 32u)) & 1u) != 0u;
+  const uint32_t excIdx = __builtin_amdgcn_mbcnt_hi(excHi, __builtin_amdgcn_mbcnt_lo(excLo, 0u));
+  const uint32_t gLast  = ng ? ng - 1u : 0u;
+  const uint32_t* cbase = stream + (size_t)(uni ? 0u : off) + lane;
   uint32_t cw[PF];
 #pragma unroll
-  for (int gi = 0; gi < PF; gi++) cw[gi] = stream_load(cbase + (size_t)min((uint32_t)gi, gLast) * cstride);
-  const int32_t base  = (int32_t)rowBase[active ? row : 0u];
-  const double xrow   = DOT ? x[min(row, nr - 1u)] : 0.0;
-  const PatEntry mine = classDict[(size_t)cls * 256 + threadIdx.x];
+  for (int gi = 0; gi < PF; gi++) cw[gi] = 0u;
+  if (!uni) {
+#pragma unroll
+    for (int gi = 0; gi < PF; gi++) cw[gi] = stream_load(cbase + (size_t)min((uint32_t)gi, gLast) * 64);
+  }
+  const int32_t base = (int32_t)rowBase[active ? row : 0u];
+  const double xrow  = DOT ? x[min(row, nr - 1u)] : 0.0;
+  PatEntry mine      = { 0.0, 0u, 0u };
+  if (dictEntries) mine = classDict[(size_t)cls * 256 + threadIdx.x];
+  const PatEntry ex0 = excRows[(size_t)excStart + threadIdx.x]; // excRows carries 512 entries of slack
+  const PatEntry ex1 = excRows[(size_t)excStart + 256u + threadIdx.x];
+  const double xpad  = x[padCol]; // slot 0: what padding multiplies (src/matrix-SCS.c:151-155)
   double t[WB];
+  if (simple) { // segment by segment: entry i of segment s -> slot first_s + i
 #pragma unroll
-  for (int k = 0; k < WB; k++) { // first (normally only) pass over the window
-    const uint32_t slot = min((uint32_t)k * 256u + threadIdx.x, winInline - 1u);
-    uint32_t col        = padCol; // slot 0: what padding multiplies (src/matrix-SCS.c:151-155)
+    for (int sI = 0; sI < 3; sI++) {
+      const uint32_t sc = field(12 + 3 * sI), sn = field(12 + 3 * sI + 2);
 #pragma unroll
-    for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++) col = slot >= segFirst[s] ? segCol[s] + (slot - segFirst[s]) : col;
-    t[k] = x[col];
+      for (int r = 0; r < 3; r++) t[sI * 3 + r] = x[sn ? sc + min((uint32_t)r * 256u + threadIdx.x, sn - 1u) : padCol];
+    }
+#pragma unroll
+    for (int sI = 3; sI < 6; sI++) {
+      const uint32_t sc = field(12 + 3 * sI), sn = field(12 + 3 * sI + 2);
+      t[6 + sI] = x[sn ? sc + min(threadIdx.x, sn - 1u) : padCol];
+    }
+  } else { // slot by slot over the inline segments
+    uint32_t segCol[PAT_INLINE_SEGS], segFirst[PAT_INLINE_SEGS];
+#pragma unroll
+    for (int s = 0; s < (int)PAT_INLINE_SEGS; s++) segCol[s] = field(12 + 3 * s), segFirst[s] = field(12 + 3 * s + 1);
+#pragma unroll
+    for (int k = 0; k < WB; k++) {
+      const uint32_t slot = min((uint32_t)k * 256u + threadIdx.x, winInline - 1u);
+      uint32_t col        = padCol;
+#pragma unroll
+      for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++) col = slot >= segFirst[s] ? segCol[s] + (slot - segFirst[s]) : col;
+      t[k] = x[col];
+    }
   }
   // keep every load above in front of the exit test (the compiler would sink them behind it)
-  asm volatile("" ::"v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]));
+  asm volatile("" ::"v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]),
+               "v"(t[8]), "v"(t[9]), "v"(t[10]), "v"(t[11]), "v"(xpad));
   asm volatile("" ::"v"(cw[0]), "v"(cw[1]), "v"(cw[2]), "v"(cw[3]), "v"(cw[4]), "v"(cw[5]), "v"(cw[6]),
                "v"(cw[7]), "v"(base), "v"(xrow), "v"(mine.v), "v"(mine.off8), "v"(mine.m));
+  asm volatile("" ::"v"(ex0.v), "v"(ex0.off8), "v"(ex1.v), "v"(ex1.off8));
   if (tile0 >= nTiles || stopped) return; // uniform per workgroup
+  if (simple) {
+    if (threadIdx.x == 0) sx[0] = xpad;
 #pragma unroll
-  for (int k = 0; k < WB; k++) {
-    const uint32_t slot = (uint32_t)k * 256u + threadIdx.x;
-    if (slot < winInline) sx[slot] = t[k];
-  }
-  for (uint32_t w0 = 256u * WB; w0 < winInline; w0 += 256u) { // windows > 2048 entries
-    const uint32_t slot = w0 + threadIdx.x;
-    uint32_t col        = padCol;
+    for (int sI = 0; sI < 3; sI++) {
+      const uint32_t sf = field(12 + 3 * sI + 1), sn = field(12 + 3 * sI + 2);
 #pragma unroll
-    for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++) col = slot >= segFirst[s] ? segCol[s] + (slot - segFirst[s]) : col;
-    if (slot < winInline) sx[slot] = x[col];
+      for (int r = 0; r < 3; r++) {
+        const uint32_t i = (uint32_t)r * 256u + threadIdx.x;
+        if (i < sn) sx[sf + i] = t[sI * 3 + r];
+      }
+    }
+#pragma unroll
+    for (int sI = 3; sI < 6; sI++) {
+      const uint32_t sf = field(12 + 3 * sI + 1), sn = field(12 + 3 * sI + 2);
+      if (threadIdx.x < sn) sx[sf + threadIdx.x] = t[6 + sI];
+    }
+  } else {
+    uint32_t segCol[PAT_INLINE_SEGS], segFirst[PAT_INLINE_SEGS];
+#pragma unroll
+    for (int s = 0; s < (int)PAT_INLINE_SEGS; s++) segCol[s] = field(12 + 3 * s), segFirst[s] = field(12 + 3 * s + 1);
+#pragma unroll
+    for (int k = 0; k < WB; k++) {
+      const uint32_t slot = (uint32_t)k * 256u + threadIdx.x;
+      if (slot < winInline) sx[slot] = t[k];
+    }
+    for (uint32_t w0 = 256u * WB; w0 < winInline; w0 += 256u) { // bigger windows
+      const uint32_t slot = w0 + threadIdx.x;
+      uint32_t col        = padCol;
+#pragma unroll
+      for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++) col = slot >= segFirst[s] ? segCol[s] + (slot - segFirst[s]) : col;
+      if (slot < winInline) sx[slot] = x[col];
+    }
+    const uint32_t segPtr = field(2);
+    for (uint32_t s = PAT_INLINE_SEGS; s < nseg; s++) { // rare: tiles with many ranges
+      const TileSeg sg = segs[segPtr + s];
+      for (uint32_t i = threadIdx.x; i < sg.len; i += 256u) sx[sg.lds + i] = x[sg.col + i];
+    }
   }
-  for (uint32_t s = PAT_INLINE_SEGS; s < nseg; s++) { // rare: tiles with many ranges
-    const TileSeg sg = segs[segPtr + s];
-    for (uint32_t i = threadIdx.x; i < sg.len; i += 256u) sx[sg.lds + i] = x[sg.col + i];
-  }
-  sd[threadIdx.x] = mine;
+  if (threadIdx.x < excCount) se[threadIdx.x] = ex0;
+  if (threadIdx.x + 256u < excCount) se[threadIdx.x + 256u] = ex1;
+  for (uint32_t i = 512u + threadIdx.x; i < excCount; i += 256u) se[i] = excRows[(size_t)excStart + i];
+  if (dictEntries) sd[threadIdx.x] = mine;
   __syncthreads();
   if (!active) return;
-  // An element costs: table entry -> byte offset of its x in the window (one multiply-add:
-  // base8 * m + off8, m = 0 for padding) -> x -> multiply -> add.  The kernel is bound by
-  // VALU issue and LDS as much as by latency, so the per-element instruction count matters:
-  // offsets are pre-scaled, and only a chunk's last, partial group pays for the
-  // "column < width" selects.
+  // An element costs: entry -> byte offset of its x in the window -> x -> multiply -> add.
+  // Offsets are pre-scaled (base8 * m + off8, m = 0 for padding), and only a chunk's last,
+  // partial group pays for the "column < width" selects.
   double acc           = 0.0;
   const uint32_t base8 = (uint32_t)base << 3;
-  auto xread = [&](uint32_t off) -> double {
-    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(sx) + off);
+  auto xread = [&](uint32_t o) -> double {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(sx) + o);
   };
   if (uni) {
-    // dominant lanes: entries of the row pattern from scalar registers; exception lanes
-    // override them per lane from their own codes and the table in LDS.  Two groups
-    // (8 columns) at a time: 8 entry loads, then the odd lanes' 8 table reads, then 8 x reads
-    // are in flight together.
+    // dominant lanes: entries of the row pattern from scalar registers (s_load through the
+    // scalar cache); exception lanes: their own ready-made entries from LDS.  Two groups
+    // (8 columns) at a time, so that 8 entry loads / 8 x reads are in flight together.
     const PatEntry* rp = rowPats + (uint32_t)__builtin_amdgcn_readlane((int)hv, 32 + (int)wv);
+    const PatEntry* me = se + ((off - excStart) + excIdx * len); // this lane's row, if it is an exception
     const bool nopad   = (lenf & PAT_NOPAD) != 0u; // wave-uniform: no padding in the dominant pattern
-    auto upair = [&](uint32_t cwa, uint32_t cwb, uint32_t j0, const bool full, const bool np) {
+    auto upair = [&](uint32_t j0, const bool full, const bool np) {
       double v[8], xs[8];
-      uint32_t off[8];
+      uint32_t o[8];
 #pragma unroll
       for (uint32_t q = 0; q < 8; q++) {
         const PatEntry e = rp[full ? j0 + q : min(j0 + q, len - 1u)]; // uniform address: s_load
@@ -664,19 +733,19 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
         const unsigned long long vs =
             (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vb) |
             ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(vb >> 32)) << 32);
-        v[q]   = __builtin_bit_cast(double, vs);
-        off[q] = np ? base8 + e.off8 : __umul24(base8, e.m) + e.off8;
+        v[q] = __builtin_bit_cast(double, vs);
+        o[q] = np ? base8 + e.off8 : __umul24(base8, e.m) + e.off8;
       }
-      if (isExc) { // divergent: only the odd lanes touch the table in LDS
+      if (isExc) { // divergent: only the odd lanes
 #pragma unroll
         for (uint32_t q = 0; q < 8; q++) {
-          const PatEntry e = sd[((q < 4 ? cwa : cwb) >> (8u * (q & 3u))) & 255u];
+          const PatEntry e = me[j0 + q]; // entries past the row's end belong to the next row / the slack
           v[q]             = e.v;
-          off[q]           = __umul24(base8, e.m) + e.off8;
+          o[q]             = e.off8;
         }
       }
 #pragma unroll
-      for (uint32_t q = 0; q < 8; q++) xs[q] = xread(off[q]);
+      for (uint32_t q = 0; q < 8; q++) xs[q] = xread(o[q]);
 #pragma unroll
       for (uint32_t q = 0; q < 8; q++) {
         const double prod = v[q] * xs[q];
@@ -684,17 +753,43 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
         acc               = (full || j0 + q < len) ? sum : acc; // wave-uniform select
       }
     };
-    auto upick = [&](uint32_t cwa, uint32_t cwb, uint32_t j0) {
-      if (j0 + 8u <= len) {
-        if (nopad) upair(cwa, cwb, j0, true, true);
-        else upair(cwa, cwb, j0, true, false);
-      } else upair(cwa, cwb, j0, false, false);
-    };
+    auto uquad = [&](uint32_t j0) { // a chunk's last 1..4 columns
+      double v[4], xs[4];
+      uint32_t o[4];
 #pragma unroll
-    for (int gi = 0; gi < PF; gi += 2)
-      if ((uint32_t)gi < ng) upick(cw[gi], cw[gi + 1], (uint32_t)gi * 4u);
-    for (uint32_t g = PF; g < ng; g += 2)
-      upick(stream_load(cbase + (size_t)g * cstride), stream_load(cbase + (size_t)min(g + 1u, gLast) * cstride), g * 4u);
+      for (uint32_t q = 0; q < 4; q++) {
+        const PatEntry e = rp[min(j0 + q, len - 1u)];
+        const unsigned long long vb = __builtin_bit_cast(unsigned long long, e.v);
+        const unsigned long long vs =
+            (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vb) |
+            ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(vb >> 32)) << 32);
+        v[q] = __builtin_bit_cast(double, vs);
+        o[q] = __umul24(base8, e.m) + e.off8;
+      }
+      if (isExc) {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+          const PatEntry e = me[j0 + q];
+          v[q]             = e.v;
+          o[q]             = e.off8;
+        }
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) xs[q] = xread(o[q]);
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) {
+        const double prod = v[q] * xs[q];
+        const double sum  = acc + prod;
+        acc               = (j0 + q < len) ? sum : acc; // wave-uniform select
+      }
+    };
+    uint32_t j0 = 0;
+    for (; j0 + 8u <= len; j0 += 8u) {
+      if (nopad) upair(j0, true, true);
+      else upair(j0, true, false);
+    }
+    if (j0 + 4u < len) upair(j0, false, false); // 5..7 columns left
+    else if (j0 < len) uquad(j0);              // 1..4 columns left
   } else {
     // per-lane codes; the 4 table reads and then the 4 x reads of a group are in flight
     // together, columns past the chunk's width are computed but not added

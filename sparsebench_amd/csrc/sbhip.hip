@@ -192,6 +192,8 @@ struct sb_matrix {
   PatEntry* classDict   = nullptr;
   TileHdr* tileHdrs     = nullptr;
   PatEntry* rowPats     = nullptr; // level 5: shared row patterns
+  PatEntry* excRows     = nullptr; // level 5: expanded exception rows of the U chunks
+  uint32_t patDict = 0, patExcLds = 0; // LDS layout of spmv_scs64_pat: table entries, exception entries
   uint32_t nRowPats = 0, nUniformChunks = 0;
   uint32_t nPatClasses  = 0;
   double patBytes       = 0.0;
@@ -680,61 +682,91 @@ static void build_patterns(sb_matrix* m)
   sb_d2h(dom.data(), dDom, (size_t)groups * sizeof(uint32_t));
   sb_d2h(exc.data(), dExc, exc.size() * sizeof(uint32_t));
   HIP_CHECK(hipFree(dDom));
-  // chunk by chunk: U (row pattern + exception lanes) or L (all 64 lanes); row patterns are
-  // shared between chunks (key: the expanded entries)
+  // chunk by chunk: U (row pattern + expanded exception lanes) or L (code words of all 64
+  // lanes); row patterns are shared between chunks (key: the expanded entries).  A tile's
+  // exception entries are staged in LDS, so a tile with too many of them stays L.
   const size_t maxPatEntries = 1u << 20; // 16 MiB of pattern rows at most
   std::vector<PatEntry> rowPats;
   std::unordered_map<std::string, uint32_t> patIndex;
   std::vector<uint32_t> chunkOff(m->nChunks), chunkFlags(m->nChunks), chunkPat(m->nChunks, 0);
+  std::vector<uint32_t> tileExcStart(nTiles, 0), tileExcCount(nTiles, 0);
   std::vector<PatEntry> row;
-  uint64_t words = 0;
+  uint64_t words = 0, excEntries = 0;
+  uint32_t excLds = 0;
+  bool anyL       = false;
   m->nUniformChunks = 0;
-  for (uint32_t c = 0; c < m->nChunks; c++) {
-    const uint32_t len = meta[c].info & 0x7FFFFFFFu, ng = (len + 3u) / 4u;
-    const uint32_t nExc = (uint32_t)__builtin_popcount(exc[2 * (size_t)c]) +
-                          (uint32_t)__builtin_popcount(exc[2 * (size_t)c + 1]);
-    bool uni = wantRows && len > 0 && nExc <= PAT_EXC_MAX, chunkNoPad = false;
-    if (uni) {
-      row.resize(len);
-      const PatEntry* cd = classDict.data() + (size_t)tileClass[c / 4] * 256;
-      bool nopad = true;
-      for (uint32_t j = 0; j < len; j++) {
-        row[j] = cd[(dom[meta[c].grp + j / 4] >> (8u * (j & 3u))) & 255u];
-        nopad  = nopad && row[j].m == 1u;
-      }
-      chunkNoPad = nopad;
-      std::string key((const char*)row.data(), row.size() * sizeof(PatEntry));
-      auto it = patIndex.find(key);
-      if (it != patIndex.end()) chunkPat[c] = it->second;
-      else if (rowPats.size() + len <= maxPatEntries) {
-        chunkPat[c] = (uint32_t)rowPats.size();
-        patIndex.emplace(std::move(key), chunkPat[c]);
-        rowPats.insert(rowPats.end(), row.begin(), row.end());
-      } else uni = false; // table full
+  auto n_exc = [&](uint32_t c) {
+    return (uint32_t)__builtin_popcount(exc[2 * (size_t)c]) + (uint32_t)__builtin_popcount(exc[2 * (size_t)c + 1]);
+  };
+  for (uint32_t t = 0; t < nTiles; t++) {
+    const uint32_t c0 = t * 4, c1 = std::min(c0 + 4, m->nChunks);
+    uint64_t tileExc = 0;
+    bool tileOk      = wantRows;
+    for (uint32_t c = c0; c < c1 && tileOk; c++) {
+      const uint32_t len = meta[c].info & 0x7FFFFFFFu;
+      if (len == 0 || n_exc(c) > PAT_EXC_MAX) continue; // this chunk will be L
+      tileExc += (uint64_t)n_exc(c) * len;
     }
-    chunkOff[c]   = (uint32_t)words;
-    chunkFlags[c] = len | (uni ? PAT_UNIFORM | (chunkNoPad ? PAT_NOPAD : 0u) : 0u);
-    words += uni ? (uint64_t)nExc * ng : (uint64_t)ng * 64u;
-    m->nUniformChunks += uni;
+    if (tileExc > PAT_EXC_LDS_MAX) tileOk = false;
+    tileExcStart[t] = (uint32_t)excEntries;
+    for (uint32_t c = c0; c < c1; c++) {
+      const uint32_t len = meta[c].info & 0x7FFFFFFFu, ng = (len + 3u) / 4u, nExc = n_exc(c);
+      bool uni = tileOk && len > 0 && nExc <= PAT_EXC_MAX, nopad = true;
+      if (uni) {
+        row.resize(len);
+        const PatEntry* cd = classDict.data() + (size_t)tileClass[t] * 256;
+        for (uint32_t j = 0; j < len; j++) {
+          row[j] = cd[(dom[meta[c].grp + j / 4] >> (8u * (j & 3u))) & 255u];
+          nopad  = nopad && row[j].m == 1u;
+        }
+        std::string key((const char*)row.data(), row.size() * sizeof(PatEntry));
+        auto it = patIndex.find(key);
+        if (it != patIndex.end()) chunkPat[c] = it->second;
+        else if (rowPats.size() + len <= maxPatEntries) {
+          chunkPat[c] = (uint32_t)rowPats.size();
+          patIndex.emplace(std::move(key), chunkPat[c]);
+          rowPats.insert(rowPats.end(), row.begin(), row.end());
+        } else uni = false; // table full
+      }
+      if (uni) {
+        chunkOff[c]   = (uint32_t)excEntries;
+        chunkFlags[c] = len | PAT_UNIFORM | (nopad ? PAT_NOPAD : 0u);
+        excEntries += (uint64_t)nExc * len;
+        tileExcCount[t] += nExc * len;
+        m->nUniformChunks++;
+      } else {
+        chunkOff[c]   = (uint32_t)words;
+        chunkFlags[c] = len;
+        words += (uint64_t)ng * 64u;
+        anyL = anyL || len > 0;
+      }
+    }
+    excLds = std::max(excLds, tileExcCount[t]);
   }
-  if (words > 0xFFFFFFFFull) {
+  if (words > 0xFFFFFFFFull || excEntries > 0xFFFFFFFFull) {
     sb_free(lanes), sb_free(dExc), sb_free(dClassKeys);
     sb_free(m->classDict), m->classDict = nullptr;
     return giveUp();
   }
   uint32_t* dOff   = (uint32_t*)upload(chunkOff.data(), chunkOff.size() * sizeof(uint32_t));
   uint32_t* dFlags = (uint32_t*)upload(chunkFlags.data(), chunkFlags.size() * sizeof(uint32_t));
-  HIP_CHECK(hipMalloc(&m->jcodes, (size_t)words * sizeof(uint32_t) + 1024)); // slack: clamped reads past the end
-  HIP_CHECK(hipMemsetAsync(m->jcodes, 0, (size_t)words * sizeof(uint32_t) + 1024, g.stream));
+  const size_t streamBytes = (size_t)words * sizeof(uint32_t) + 1024;          // slack: clamped reads
+  const size_t excBytes    = ((size_t)excEntries + 520) * sizeof(PatEntry);     // slack: 2 x 256 unconditional reads
+  HIP_CHECK(hipMalloc(&m->jcodes, streamBytes));
+  HIP_CHECK(hipMalloc(&m->excRows, excBytes));
+  HIP_CHECK(hipMemsetAsync(m->jcodes, 0, streamBytes, g.stream));
+  HIP_CHECK(hipMemsetAsync(m->excRows, 0, excBytes, g.stream));
   hipLaunchKernelGGL(pat_compact_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dOff,
-      dFlags, dExc, m->jcodes);
+      dFlags, dExc, m->rowBase, m->tileClass, m->classDict, m->jcodes, m->excRows);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(g.stream));
   sb_free(lanes), sb_free(dExc), sb_free(dOff), sb_free(dFlags), sb_free(dClassKeys);
-  if (rowPats.empty()) rowPats.push_back(PatEntry{ 0.0, 0, 0u });
+  if (rowPats.empty()) rowPats.push_back(PatEntry{ 0.0, 0u, 0u });
   m->rowPats     = (PatEntry*)upload(rowPats.data(), rowPats.size() * sizeof(PatEntry));
   m->nRowPats    = (uint32_t)patIndex.size();
   m->nPatClasses = (uint32_t)classes.size();
+  m->patDict     = anyL ? 256u : 0u;
+  m->patExcLds   = excLds;
   // one header per tile: class, chunk positions / widths / row patterns, the first segments
   std::vector<uint32_t> segPtr(nTiles + 1);
   sb_d2h(segPtr.data(), m->tileSegPtr, segPtr.size() * sizeof(uint32_t));
@@ -746,6 +778,7 @@ static void build_patterns(sb_matrix* m)
     TileHdr& h = hdrs[t];
     memset(&h, 0, sizeof h);
     h.cls = tileClass[t], h.nseg = segPtr[t + 1] - segPtr[t], h.segPtr = segPtr[t], h.win = 1;
+    h.excStart = tileExcStart[t], h.excCount = tileExcCount[t];
     for (uint32_t w = 0; w < 4; w++) {
       const uint32_t c = t * 4 + w;
       if (c >= m->nChunks) continue;
@@ -754,18 +787,33 @@ static void build_patterns(sb_matrix* m)
     }
     for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++) h.seg[s][1] = 0xFFFFFFFFu;
     h.winInline = 1;
+    // simple window: <= 6 segments which, longest first, are 3 x <= 768 and 3 x <= 256 entries
+    std::vector<TileSeg> ts(segs.begin() + segPtr[t], segs.begin() + segPtr[t] + h.nseg);
+    std::stable_sort(ts.begin(), ts.end(), [](const TileSeg& a, const TileSeg& b) { return a.len > b.len; });
+    bool simple = h.nseg <= PAT_INLINE_SEGS;
+    for (uint32_t s = 0; s < h.nseg && simple; s++) simple = ts[s].len <= (s < 3 ? 768u : 256u);
+    for (uint32_t s = 0; s < h.nseg; s++) {
+      const TileSeg& sg = simple ? ts[s] : segs[segPtr[t] + s]; // slot order unless simple
+      if (s < PAT_INLINE_SEGS) h.seg[s][0] = sg.col, h.seg[s][1] = sg.lds, h.seg[s][2] = sg.len;
+    }
     for (uint32_t s = 0; s < h.nseg; s++) {
       const TileSeg& sg = segs[segPtr[t] + s];
-      if (s < PAT_INLINE_SEGS) {
-        h.seg[s][0] = sg.col, h.seg[s][1] = sg.lds, h.seg[s][2] = sg.len;
-        h.winInline = sg.lds + sg.len;
-      }
+      if (s < PAT_INLINE_SEGS) h.winInline = sg.lds + sg.len;
       h.win = sg.lds + sg.len;
     }
+    h.flags = simple ? PAT_SIMPLE_WINDOW : 0u;
   }
   m->tileHdrs = (TileHdr*)upload(hdrs.data(), hdrs.size() * sizeof(TileHdr));
-  m->patBytes = (double)words * 4.0 + 2.0 * 64.0 * m->nChunks + 16.0 * nSegs + (double)sizeof(TileHdr) * nTiles +
-                4096.0 * classes.size() + 16.0 * rowPats.size();
+  if (getenv("SB_PACK_REPORT")) {
+    size_t nSimple = 0;
+    for (const TileHdr& h : hdrs) nSimple += h.flags & PAT_SIMPLE_WINDOW;
+    fprintf(stderr, "sbhip pack: %u tiles (%zu simple windows, max %u entries), %u classes, %u/%u U chunks, "
+                    "%zu row patterns (%zu entries), %llu exception entries (max %u per tile), %llu code words\n",
+        nTiles, nSimple, m->ldsWindow, m->nPatClasses, m->nUniformChunks, m->nChunks, patIndex.size(),
+        rowPats.size(), (unsigned long long)excEntries, excLds, (unsigned long long)words);
+  }
+  m->patBytes = (double)words * 4.0 + 16.0 * (double)excEntries + 2.0 * 64.0 * m->nChunks + 16.0 * nSegs +
+                (double)sizeof(TileHdr) * nTiles + (anyL ? 4096.0 * classes.size() : 0.0) + 16.0 * rowPats.size();
   m->usePacked = 3; // 3: pattern codes / row patterns + x window in LDS
 }
 
@@ -826,7 +874,7 @@ void sb_matrix_free(sb_matrix* m)
   sb_free(m->oldToNew), sb_free(m->newToOld), sb_free(m->colInd), sb_free(m->val);
   sb_free(m->pmeta), sb_free(m->pidx), sb_free(m->pcodes), sb_free(m->pdict);
   sb_free(m->tileSegPtr), sb_free(m->tileSegs), sb_free(m->pslots);
-  sb_free(m->rowBase), sb_free(m->tileClass), sb_free(m->jcodes), sb_free(m->classDict), sb_free(m->tileHdrs), sb_free(m->rowPats);
+  sb_free(m->rowBase), sb_free(m->tileClass), sb_free(m->jcodes), sb_free(m->classDict), sb_free(m->tileHdrs), sb_free(m->rowPats), sb_free(m->excRows);
   delete m;
 }
 
@@ -895,16 +943,16 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
     const uint32_t per     = g_scs_xcd ? (nBlocks + 7) / 8 : 0;
     dim3 grid(g_scs_xcd ? per * 8 : nBlocks), block(256);
     if (m->usePacked == 3) {
-      const size_t shmem = (512 + (size_t)m->ldsWindow) * sizeof(double);
+      const size_t shmem = ((size_t)m->patDict + m->patExcLds + 8) * sizeof(PatEntry) + (size_t)m->ldsWindow * sizeof(double);
       if (!stop) stop = zero_flag();
       if (dot)
         hipLaunchKernelGGL((spmv_scs64_pat<true>), grid, block, shmem, g.stream, m->tileHdrs, m->jcodes,
-            m->rowBase, m->classDict, m->rowPats, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol,
-            dotPartials, stop);
+            m->rowBase, m->classDict, m->rowPats, m->excRows, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol,
+            m->patDict, m->patExcLds, dotPartials, stop);
       else
         hipLaunchKernelGGL((spmv_scs64_pat<false>), grid, block, shmem, g.stream, m->tileHdrs, m->jcodes,
-            m->rowBase, m->classDict, m->rowPats, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol,
-            dotPartials, stop);
+            m->rowBase, m->classDict, m->rowPats, m->excRows, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol,
+            m->patDict, m->patExcLds, dotPartials, stop);
     } else if (m->usePacked == 2) {
       const size_t shmem = (256 + (size_t)m->ldsWindow) * sizeof(double);
 #define LDS_LAUNCH(DI, DO)                                                                                   \
