@@ -700,10 +700,15 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
       for (uint32_t i = threadIdx.x; i < sg.len; i += 256u) sx[sg.lds + i] = x[sg.col + i];
     }
   }
-  if (threadIdx.x < excCount) se[threadIdx.x] = ex0;
-  if (threadIdx.x + 256u < excCount) se[threadIdx.x + 256u] = ex1;
-  for (uint32_t i = 512u + threadIdx.x; i < excCount; i += 256u) se[i] = excRows[(size_t)excStart + i];
-  if (dictEntries) sd[threadIdx.x] = mine;
+  // offsets become LDS byte addresses here (once per staged entry, not once per use)
+  const uint32_t sxOff = (dictEntries + excLds + 8u) * (uint32_t)sizeof(PatEntry);
+  if (threadIdx.x < excCount) se[threadIdx.x] = PatEntry{ ex0.v, ex0.off8 + sxOff, 0u };
+  if (threadIdx.x + 256u < excCount) se[threadIdx.x + 256u] = PatEntry{ ex1.v, ex1.off8 + sxOff, 0u };
+  for (uint32_t i = 512u + threadIdx.x; i < excCount; i += 256u) {
+    const PatEntry e = excRows[(size_t)excStart + i];
+    se[i]            = PatEntry{ e.v, e.off8 + sxOff, 0u };
+  }
+  if (dictEntries) sd[threadIdx.x] = PatEntry{ mine.v, mine.off8 + sxOff, mine.m };
   __syncthreads();
   if (!active) return;
   // An element costs: entry -> byte offset of its x in the window -> x -> multiply -> add.
@@ -711,9 +716,10 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   // partial group pays for the "column < width" selects.
   double acc           = 0.0;
   const uint32_t base8 = (uint32_t)base << 3;
-  auto xread = [&](uint32_t o) -> double {
-    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(sx) + o);
+  auto xread = [&](uint32_t o) -> double { // o: LDS byte address
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds) + o);
   };
+  const uint32_t base8x = base8 + sxOff;
   if (uni) {
     // dominant lanes: entries of the row pattern from scalar registers (s_load through the
     // scalar cache); exception lanes: their own ready-made entries from LDS.  Two groups
@@ -734,7 +740,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
             (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vb) |
             ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(vb >> 32)) << 32);
         v[q] = __builtin_bit_cast(double, vs);
-        o[q] = np ? base8 + e.off8 : __umul24(base8, e.m) + e.off8;
+        o[q] = np ? base8x + e.off8 : __umul24(base8, e.m) + (e.off8 + sxOff);
       }
       if (isExc) { // divergent: only the odd lanes
 #pragma unroll
@@ -764,7 +770,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
             (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vb) |
             ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(vb >> 32)) << 32);
         v[q] = __builtin_bit_cast(double, vs);
-        o[q] = __umul24(base8, e.m) + e.off8;
+        o[q] = __umul24(base8, e.m) + (e.off8 + sxOff);
       }
       if (isExc) {
 #pragma unroll
