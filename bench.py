@@ -32,6 +32,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guides/MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+    (profiles/*_pmc_traffic.json, newest first) -- PMC counters cannot be collected from inside the
+    run; None when no pass exists for this workload / kernel."""
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json")), reverse=True) \
+            if os.path.isdir(pdir) else []:
+        try:
+            e = json.load(open(os.path.join(pdir, name))).get(workload, {}).get(kernel)
+        except (OSError, ValueError):
+            continue
+        if e:
+            return e["bytes_per_launch"], "profiles/" + name
+    return None, None
 SEGMENT = 120          # iterations per timed segment (keeps r.r far from underflow)
 
 
@@ -245,6 +261,10 @@ def main():
         achieved = spmv_bytes / (spmv_us * 1e-6) / 1e9 if spmv_n else 0.0
         nnz_true = prob.nnzTrue
         cg_bytes = 96.0 * prob.nr + spmv_bytes  # reference's unfused op list
+        workload = "hpcg_27pt_%d^3_per_gpu_%s_C%d_sigma%d" % (n, args.fmt, args.C, args.sigma)
+        kernel = ("spmv_crs_stream" if args.fmt == "crs" else
+                  ["spmv_scs64", "spmv_scs64_packed", "spmv_scs64_lds", "spmv_scs64_pat"][mode])
+        traffic, traffic_src = pmc_traffic(workload, kernel) if world == 1 else (None, None)
         out = {
             "metric": "cg_iterations_per_s",
             "value": world * it_s,
@@ -253,7 +273,7 @@ def main():
             "ms_per_step": 1e3 * t_clean / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "hpcg_27pt_%d^3_per_gpu_%s_C%d_sigma%d" % (n, args.fmt, args.C, args.sigma),
+            "config": {"workload": workload,
                        "rows_per_gpu": prob.nr, "nnz_per_gpu": nnz_true, "index_type": "u32",
                        "parallelism": "1d_block_row_x%d" % world, "fused_dots": True,
                        "hip_graph": bool(args.graph)},
@@ -261,10 +281,9 @@ def main():
             "cg_algorithmic_GBs_per_gpu": cg_bytes * it_s / 1e9,
             "cg_frac_of_hbm_peak": cg_bytes * it_s / 1e9 / HBM_PEAK_GBS,
             "roofline": {"bound": "hbm",
-                         "kernel": ("spmv_crs_stream" if args.fmt == "crs" else
-                                    ["spmv_scs64", "spmv_scs64_packed", "spmv_scs64_lds", "spmv_scs64_pat"][mode]),
+                         "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": spmv_bytes,
                          "moved_bytes_per_launch": moved_bytes,
                          "moved_GBs": moved_bytes / (spmv_us * 1e-6) / 1e9 if spmv_n else 0.0,
@@ -283,6 +302,7 @@ def main():
                 "bound": "hbm", "kernel": "spmv_scs64", "achieved": spmv_bytes / (ref_us * 1e-6) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_bytes / (ref_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "avg_launch_us": ref_us, "launches_timed": ref_n,
+                "traffic": pmc_traffic(workload, "spmv_scs64")[0] if world == 1 else None,
                 "cg_iterations_per_s": world * K / t_ref}
         out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

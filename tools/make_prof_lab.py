@@ -34,7 +34,7 @@ patch(W + "/sparsebench_amd/csrc/pack.hip.h", [
     ("  const int stopped    = (int)field(PAT_STOP_LANE);\n", "  const int stopped    = (int)field(PAT_STOP_LANE);\n  PROF(1);\n"),
     ("  if (tile0 >= nTiles || stopped) return; // uniform per workgroup\n",
      "  if (tile0 >= nTiles || stopped) return; // uniform per workgroup\n  PROF(2);\n"),
-    ("  if (dictEntries) sd[threadIdx.x] = mine;\n  __syncthreads();\n", "  if (dictEntries) sd[threadIdx.x] = mine;\n  __syncthreads();\n  PROF(3);\n"
+    ("mine.off8 + sxOff, mine.m };\n  __syncthreads();\n", "mine.off8 + sxOff, mine.m };\n  __syncthreads();\n  PROF(3);\n"
      "#ifdef LAB_EXIT_AFTER_BARRIER\n  if (row < nr) y[row] = xrow + (double)base + sx[lane] + se[lane].v;\n  return;\n#endif\n"),
     ("  if (row < nr) y[row] = acc;\n  if (DOT) {\n    double t2", "  PROF(4);\n  if (row < nr) y[row] = acc;\n  if (DOT) {\n    double t2"),
 ])

@@ -28,8 +28,20 @@ if lines:
     with open(os.path.join(out, "%s_pmc_summary.txt" % tag), "w") as f:
         f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), per-launch values in KiB as\n"
                 "# reported.  gfx950: FETCH_SIZE counts HALF the bytes of coalesced reads (guide: MI355X_MICROARCH\n"
-                "# 'HBM'); calibrated here on cg_update_p (2 x 16 MiB read -> 16397 KiB reported) and\n"
-                "# cg_update_xr_dot (4 x 16 MiB -> 32786 KiB): factor 2.00 for 4-, 8- and 16-byte-per-lane loads.\n"
-                "# WRITE_SIZE is exact.\n")
+                "# 'HBM'); calibration on kernels with known byte counts at 128^3 (nr = 2097152): dot_spans_k<3>\n"
+                "# reads r and Ap = 2 x 16 MiB and reports ~16.4k KiB, cg_update_p reads r, p, x = 3 x 16 MiB and\n"
+                "# reports ~24.6k KiB: factor 2.00.  WRITE_SIZE is exact.\n")
         f.write("\n".join(lines) + "\n")
-print("wrote", os.listdir(out))
+path = os.path.join(src, "sq", "r1_counter_collection.csv")
+if os.path.exists(path):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    with open(os.path.join(out, "%s_sq_counters.txt" % tag), "w") as f:
+        f.write("# rocprofv3 --pmc (SQ block, own pass), per-launch means summed over the GPU; WAVE_CYCLES and\n"
+                "# *_ACTIVE in units of 4 clocks; spmv_scs64_pat runs 32768 waves per launch at 128^3\n")
+        for (k, c), v in sorted(agg.items()):
+            if k.startswith("__amd") or "pack" in k or "pat_" in k or "remap" in k:
+                continue
+            f.write("%-44s %-22s launches=%4d mean=%.4g\n" % (k[-44:], c, len(v), sum(v) / len(v)))
+print("wrote", sorted(os.listdir(out)))
