@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=480)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=128, help="brick edge per GPU")
+    ap.add_argument("--n", "--grid", dest="n", type=int, default=128, help="brick edge per GPU")
     ap.add_argument("--fmt", default="scs", choices=["scs", "crs"])
     ap.add_argument("--C", type=int, default=64)
     ap.add_argument("--sigma", type=int, default=256)
@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--pack-mode", type=int, default=3,
                     help="SpMV stream: 0 reference layout, 1 compressed, 2 compressed + LDS x-window, "
                          "3 pattern codes + LDS x-window (default: best available)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+                    help="N > 1 data plane: rccl (production) or host (gloo-staged; lets N ranks share one GPU "
+                         "to rehearse the multi-rank flow -- its numbers are not a benchmark)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=60)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
@@ -176,10 +179,16 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from sparsebench_amd import capi, hostapi
-    L = capi.init(local)
+    capi.load()
+    ndev = capi.load().sb_device_count()
+    L = capi.init(local % ndev if args.transport == "host" and ndev > 0 else local)
     H = hostapi.host()
 
-    if world > 1:
+    keep = None
+    if world > 1 and args.transport == "host":
+        from sparsebench_amd import gloo_transport
+        keep = gloo_transport.attach(L, H, dist, rank, world)  # noqa: F841
+    elif world > 1:
         import torch
         idbuf = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
@@ -268,14 +277,17 @@ def main():
         out = {
             "metric": "cg_iterations_per_s",
             "value": world * it_s,
-            "unit": "iterations/s (one iteration = one 128^3-brick CG step; summed over GPUs)",
+            "unit": "iterations/s (one iteration = one %d^3-brick CG step; summed over GPUs)" % n,
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * t_clean / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload,
                        "rows_per_gpu": prob.nr, "nnz_per_gpu": nnz_true, "index_type": "u32",
-                       "parallelism": "1d_block_row_x%d" % world, "fused_dots": True,
+                       "parallelism": "1d_block_row_x%d" % world,
+                       "transport": ("none" if world == 1 else "rccl_xgmi" if args.transport == "rccl"
+                                     else "host_staged_gloo (rehearsal)"),
+                       "fused_dots": True,
                        "hip_graph": bool(args.graph)},
             "global_iterations_per_s": it_s,
             "cg_algorithmic_GBs_per_gpu": cg_bytes * it_s / 1e9,

@@ -1,0 +1,93 @@
+"""Host-mediated transport over torch.distributed (gloo) for the multi-rank device path.
+
+The production data plane is RCCL inside libsbhip.so (sb_comm_init).  A launcher without
+RCCL -- or several ranks sharing one GPU, which RCCL refuses -- supplies two callbacks instead
+(include/sbhip.h: sb_transport, sb_comm_init_transport) and an sbh_exchange for the setup
+traffic of commPartition.  This module is that launcher-side glue for torch.distributed:
+device buffers are staged through the host, gloo moves them.  Used by
+tests/gpu_multirank_worker.py and by `bench.py --transport host` (rehearsal of the N-rank
+bench flow on one GPU); correct, not fast.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi, hostapi
+
+vp = C.c_void_p
+
+
+def attach(L, H, dist, rank, size):
+    """Install the setup exchange (H.commSetExchange) and the run-time transport
+    (L.sb_comm_init_transport).  Returns the ctypes objects that must stay alive."""
+    import torch
+
+    def allgather(ctx, mine, cnt, out):
+        t = torch.tensor([mine[i] for i in range(cnt)], dtype=torch.int32)
+        outs = [torch.zeros(cnt, dtype=torch.int32) for _ in range(size)]
+        dist.all_gather(outs, t)
+        for i, v in enumerate(torch.cat(outs).tolist()):
+            out[i] = v
+
+    def alltoallv(ctx, sbuf, scnt, sdsp, rbuf, rcnt, rdsp):
+        reqs, recv = [], {}
+        for r in range(size):
+            if r == rank:
+                continue
+            if scnt[r]:
+                reqs.append(dist.isend(torch.tensor([sbuf[sdsp[r] + i] for i in range(scnt[r])], dtype=torch.int32), r))
+            if rcnt[r]:
+                recv[r] = torch.zeros(rcnt[r], dtype=torch.int32)
+                reqs.append(dist.irecv(recv[r], r))
+        for q in reqs:
+            q.wait()
+        for r, t in recv.items():
+            for i, v in enumerate(t.tolist()):
+                rbuf[rdsp[r] + i] = v
+
+    def d2h(ptr, count):
+        a = np.empty(count, dtype=np.float64)
+        if count:
+            L.sb_d2h(a.ctypes.data_as(vp), ptr, count * 8)
+        return a
+
+    def allreduce(ctx, v_dev, op):
+        mine = torch.from_numpy(d2h(v_dev, 1))
+        outs = [torch.zeros(1, dtype=torch.float64) for _ in range(size)]
+        dist.all_gather(outs, mine)
+        vals = [float(t[0]) for t in outs]
+        if op == 0:
+            res = max(vals)
+        else:  # pairwise tree == recursive doubling of the MPI reference run
+            while len(vals) > 1:
+                nxt = [vals[i] + vals[i + 1] for i in range(0, len(vals) - 1, 2)]
+                if len(vals) & 1:
+                    nxt.append(vals[-1])
+                vals = nxt
+            res = vals[0]
+        out = np.array([res])
+        L.sb_h2d(v_dev, out.ctypes.data_as(vp), 8)
+
+    def exchange(ctx, send_dev, outdeg, dests, scnt, sdsp, recv_dev, indeg, srcs, rcnt, rdsp):
+        total = sum(scnt[i] for i in range(outdeg))
+        sbuf = d2h(send_dev, total)
+        reqs, bufs = [], []
+        for i in range(outdeg):
+            reqs.append(dist.isend(torch.from_numpy(sbuf[sdsp[i]:sdsp[i] + scnt[i]].copy()), dests[i]))
+        for j in range(indeg):
+            t = torch.zeros(rcnt[j], dtype=torch.float64)
+            bufs.append((rdsp[j], t))
+            reqs.append(dist.irecv(t, srcs[j]))
+        for q in reqs:
+            q.wait()
+        for off, t in bufs:
+            a = t.numpy()
+            L.sb_h2d(recv_dev + off * 8, a.ctypes.data_as(vp), len(a) * 8)
+
+    cb1, cb2 = hostapi.ALLGATHER_FN(allgather), hostapi.ALLTOALLV_FN(alltoallv)
+    xchg = hostapi.ExchangeS(None, cb1, cb2)
+    H.commSetExchange(C.byref(xchg))
+    cb3, cb4 = capi.ALLREDUCE_FN(allreduce), capi.EXCHANGE_FN(exchange)
+    tr = capi.TransportS(None, cb3, cb4)
+    L.sb_comm_init_transport(rank, size, C.byref(tr))
+    return (cb1, cb2, xchg, cb3, cb4, tr)
