@@ -181,6 +181,14 @@ void commBarrier(void);
 void MMMatrixRead(MMMatrix* m, char* filename);
 void matrixConvertfromMM(MMMatrix* mm, GMatrix* m);
 void matrixGenerate(GMatrix* m, Parameter* p, int rank, int size, bool use_7pt_stencil);
+/* binary matrix files, src/matrixBinfile.h:21-22 (same bytes; plain POSIX I/O instead of MPI-IO;
+ * SB_BMX_FP64=1 writes the fp64 extension, the reader accepts both) */
+void matrixBinWrite(GMatrix* m, Comm* c, char* filename);
+void matrixBinRead(GMatrix* m, Comm* c, char* filename);
+/* the driver's matrix set-up, src/main.c:54-84 (generate | generate7P | .mtx | .bmx), and its
+ * `-c file.mtx` conversion, src/main.c:41-52 */
+void sbh_init_matrix(Comm* c, Parameter* p, GMatrix* m);
+void sbh_write_bin_matrix(Comm* c, char* mtxFilename);
 void* allocate(size_t alignment, size_t bytesize); /* src/allocate.h:9 (host memory) */
 double getTimeStamp(void);                          /* src/timing.h */
 

@@ -36,16 +36,7 @@ sbh_problem* sbh_problem_create(const char* filename, int nx, int ny, int nz, in
   p->par.nx = nx, p->par.ny = ny, p->par.nz = nz;
   p->comm.rank = rank, p->comm.size = size;
   p->generated = strcmp(filename, "generate") == 0 || strcmp(filename, "generate7P") == 0;
-  if (p->generated) {
-    matrixGenerate(&p->gm, &p->par, rank, size, strcmp(filename, "generate7P") == 0);
-  } else {
-    MMMatrix mm, local;
-    memset(&mm, 0, sizeof mm), memset(&local, 0, sizeof local);
-    MMMatrixRead(&mm, p->par.filename);
-    commDistributeMatrix(&p->comm, &mm, &local);
-    matrixConvertfromMM(&local, &p->gm);
-    free(mm.entries);
-  }
+  sbh_init_matrix(&p->comm, &p->par, &p->gm);
   p->nnzTrue = p->gm.rowPtr[p->gm.nr];
   commPartition(&p->comm, &p->gm);
   if (fmt == 0) {
@@ -116,6 +107,58 @@ const void* sbh_problem_array(sbh_problem* p, int which)
   case 15: return p->comm.externalGlobal;
   default: return NULL;
   }
+}
+
+/* `file.mtx` -> `file.bmx` next to it, as the driver's -c option (src/main.c:41-52); no device needed */
+void sbh_convert_mtx_to_bmx(const char* mtxFilename)
+{
+  Comm c;
+  memset(&c, 0, sizeof c);
+  c.size = 1;
+  char* name = strdup(mtxFilename);
+  sbh_write_bin_matrix(&c, name);
+  free(name);
+}
+
+/* one rank's row slice of a .bmx file, before commPartition (global column ids) */
+typedef struct {
+  GMatrix gm;
+} sbh_gm;
+
+sbh_gm* sbh_bmx_read(const char* filename, int rank, int size)
+{
+  sbh_gm* g = (sbh_gm*)calloc(1, sizeof *g);
+  Comm c;
+  memset(&c, 0, sizeof c);
+  c.rank = rank, c.size = size;
+  char* name = strdup(filename);
+  matrixBinRead(&g->gm, &c, name);
+  free(name);
+  return g;
+}
+
+unsigned sbh_gm_scalar(sbh_gm* g, int which)
+{
+  switch (which) {
+  case 0: return g->gm.nr;
+  case 1: return g->gm.nnz;
+  case 2: return g->gm.startRow;
+  case 3: return g->gm.stopRow;
+  case 4: return g->gm.totalNr;
+  default: return g->gm.totalNnz;
+  }
+}
+
+void sbh_gm_copy(sbh_gm* g, unsigned* rowPtr, unsigned* col, double* val)
+{
+  for (CG_UINT i = 0; i <= g->gm.nr; i++) rowPtr[i] = g->gm.rowPtr[i];
+  for (CG_UINT i = 0; i < g->gm.nnz; i++) col[i] = g->gm.entries[i].col, val[i] = g->gm.entries[i].val;
+}
+
+void sbh_gm_free(sbh_gm* g)
+{
+  if (!g) return;
+  free(g->gm.rowPtr), free(g->gm.entries), free(g);
 }
 
 const double* sbh_problem_values(sbh_problem* p) { return p->fmt == 0 ? p->crs.val : p->scs.val; }

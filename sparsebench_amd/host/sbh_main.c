@@ -5,7 +5,8 @@
  *   - SCS gets -C <chunk height> and -s <sigma> (the reference has no flag, and no
  *     working SCS path);
  *   - -t spmv allocates x and y in HBM (sb_malloc) so the loop times the kernel;
- *   - -c (.bmx conversion) is not part of the hot path and is refused.
+ *   - .bmx files (-c <file.mtx> writes one, -m <file.bmx> loads one) go through plain
+ *     POSIX I/O instead of MPI-IO (sbh_binfile.c); SB_BMX_FP64=1 keeps fp64 values.
  */
 #define _GNU_SOURCE
 #include <ctype.h>
@@ -22,7 +23,8 @@ static const char* kHelp =
     "Options:\n"
     "  -h         Show this help text\n"
     "  -f <parameter file>   Load options from a parameter file\n"
-    "  -m <MM matrix>   Load a matrix market file\n"
+    "  -c <file name>   Convert MM matrix to binary matrix file (.bmx).\n"
+    "  -m <matrix>   Load a matrix market (.mtx) or binary (.bmx) file\n"
     "  -t <bench type>   Benchmark type, can be cg or spmv. Default cg.\n"
     "  -x <int>   Size in x for generated matrix, ignored if MM file is loaded. Default 100.\n"
     "  -y <int>   Size in y for generated matrix, ignored if MM file is loaded. Default 100.\n"
@@ -31,29 +33,6 @@ static const char* kHelp =
     "  -e <float>  Convergence criteria epsilon. Default 0.0.\n"
     "  -C <int>   Sell-C-sigma chunk height (SCS build). Default 64.\n"
     "  -s <int>   Sell-C-sigma sorting scope (SCS build). Default 1.\n";
-
-static void initMatrix(Comm* c, Parameter* p, GMatrix* m)
-{
-  if (strcmp(p->filename, "generate") == 0) {
-    matrixGenerate(m, p, c->rank, c->size, false);
-  } else if (strcmp(p->filename, "generate7P") == 0) {
-    matrixGenerate(m, p, c->rank, c->size, true);
-  } else {
-    const char* dot = strrchr(p->filename, '.');
-    if (dot && strcmp(dot, ".mtx") == 0) {
-      MMMatrix mm, local;
-      memset(&mm, 0, sizeof mm), memset(&local, 0, sizeof local);
-      if (commIsMaster(c)) printf("Read MTX matrix\n");
-      MMMatrixRead(&mm, p->filename);
-      commDistributeMatrix(c, &mm, &local);
-      matrixConvertfromMM(&local, m);
-      free(mm.entries);
-    } else {
-      printf("Unknown matrix file format!\n");
-      commAbort(c, "Only generate, generate7P and .mtx inputs are supported");
-    }
-  }
-}
 
 int main(int argc, char** argv)
 {
@@ -69,7 +48,10 @@ int main(int argc, char** argv)
       if (commIsMaster(&comm)) printf("%s", kHelp);
       commAbort(&comm, "");
       break;
-    case 'c': commAbort(&comm, "-c (.bmx conversion) is outside the HIP hot path"); break;
+    case 'c':
+      sbh_write_bin_matrix(&comm, optarg); /* src/main.c:107-110 */
+      commAbort(&comm, "Finish write matrix");
+      break;
     case 'f': readParameter(&param, optarg); break;
     case 'm': param.filename = optarg; break;
     case 't':
@@ -99,7 +81,7 @@ int main(int argc, char** argv)
   double ts;
   GMatrix m;
   double timeStart = getTimeStamp();
-  initMatrix(&comm, &param, &m);
+  sbh_init_matrix(&comm, &param, &m);
   commPartition(&comm, &m);
   Matrix sm;
   memset(&sm, 0, sizeof sm);

@@ -59,15 +59,7 @@ int main(int argc, char** argv)
     }
   commPrintBanner(&comm);
   GMatrix g;
-  if (strcmp(param.filename, "generate") == 0) {
-    matrixGenerate(&g, &param, comm.rank, comm.size, false);
-  } else {
-    MMMatrix mm, local;
-    memset(&mm, 0, sizeof mm), memset(&local, 0, sizeof local);
-    MMMatrixRead(&mm, param.filename);
-    commDistributeMatrix(&comm, &mm, &local);
-    matrixConvertfromMM(&local, &g);
-  }
+  sbh_init_matrix(&comm, &param, &g);
   const double nnzTrue = (double)g.rowPtr[g.nr];
   commPartition(&comm, &g);
   Matrix m;

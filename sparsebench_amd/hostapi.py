@@ -50,6 +50,8 @@ def host():
     H.sbh_problem_values.restype = vp
     H.sbh_problem_values.argtypes = [vp]
     H.sbh_problem_gm_entries.argtypes = [vp, vp, vp]
+    H.sbh_convert_mtx_to_bmx.restype = None
+    H.sbh_convert_mtx_to_bmx.argtypes = [C.c_char_p]
     H.sbh_problem_rhs.restype = C.c_int
     H.sbh_problem_rhs.argtypes = [vp, vp, vp]
     H.sbh_problem_free.argtypes = [vp]
@@ -66,6 +68,29 @@ _ARRAYS = {"rowPtr": 0, "rowNnz": 1, "crs_colInd": 2, "chunkPtr": 3, "chunkLens"
            "scs_colInd": 5, "oldToNewPerm": 6, "newToOldPerm": 7, "elementsToSend": 8,
            "sources": 9, "recvCounts": 10, "rdispls": 11, "destinations": 12, "sendCounts": 13,
            "sdispls": 14, "externalGlobal": 15}
+
+
+def convert_mtx_to_bmx(path):
+    """file.mtx -> file.bmx next to it (the driver's -c option); SB_BMX_FP64=1 keeps fp64 values"""
+    host().sbh_convert_mtx_to_bmx(os.fspath(path).encode())
+    return os.path.splitext(os.fspath(path))[0] + ".bmx"
+
+
+def read_bmx_slice(path, rank=0, size=1):
+    """rank's row slice of a .bmx file as (startRow, rowPtr, col, val), global column ids"""
+    H = host()
+    H.sbh_bmx_read.restype = vp
+    H.sbh_bmx_read.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    H.sbh_gm_scalar.restype = C.c_uint
+    H.sbh_gm_scalar.argtypes = [vp, C.c_int]
+    H.sbh_gm_copy.argtypes = [vp, vp, vp, vp]
+    H.sbh_gm_free.argtypes = [vp]
+    g = H.sbh_bmx_read(os.fspath(path).encode(), rank, size)
+    nr, nnz, start = (H.sbh_gm_scalar(g, i) for i in range(3))
+    rp, col, val = np.empty(nr + 1, np.uint32), np.empty(nnz, np.uint32), np.empty(nnz, np.float64)
+    H.sbh_gm_copy(g, rp.ctypes.data_as(vp), col.ctypes.data_as(vp), val.ctypes.data_as(vp))
+    H.sbh_gm_free(g)
+    return start, rp, col, val
 
 
 def _view(ptr, n, dtype):

@@ -104,9 +104,28 @@ def scs_fix():
     json.dump(out, open(os.path.join(OUT, "scs_layout_fix.json"), "w"), indent=0)
 
 
+def bmx():
+    """binary matrix files written by the reference's own `-c <file.mtx>` (src/main.c:41-52 ->
+    src/matrixBinfile.c:38-104, built unmodified into oracle/_ref/sb_ref_mpi): tests/golden/ref/*.bmx"""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "sb_ref_mpi")
+    if not os.path.exists(exe):
+        print("bmx: no sb_ref_mpi (no MPI compiler wrapper) -- skipped")
+        return
+    with tempfile.TemporaryDirectory() as tmp:
+        for nm in ("matrix_band_klein", "test0", "test8"):
+            shutil.copy(os.path.join(REFD, nm + ".mtx"), tmp)
+            subprocess.run([exe, "-c", os.path.join(tmp, nm + ".mtx")], cwd=tmp, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, check=False)  # exits through commAbort
+            shutil.copy(os.path.join(tmp, nm + ".bmx"), os.path.join(OUT, "ref", nm + ".bmx"))
+
+
 if __name__ == "__main__":
     po.build()
     one_rank()
     mpi()
     spmv()
     scs_fix()
+    bmx()

@@ -79,3 +79,24 @@ def test_benchmark_executable_cli(gpu, golden_1rank):
     open(par, "w").write("filename generate #Space is required after string!\nnx 8\nny 8\nnz 8\nitermax 20\neps 0.0\n")
     out = subprocess.run([os.path.join(BIN, "sparseBench-CRS-HIP"), "-f", par], stdout=subprocess.PIPE, timeout=300)
     assert "Initial Residual = 2.084418E+02" in out.stdout.decode()  # BASELINE.md, HPCG 8^3
+
+
+def test_driver_binary_matrix_files(gpu, tmp_path):
+    """-c file.mtx writes the reference's .bmx bytes; -m file.bmx runs CG on it: same lines as the
+    .mtx run (matrix_band_klein: every value is exactly representable in the file's float32)"""
+    import shutil
+    mtx = tmp_path / "matrix_band_klein.mtx"
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "ref", "matrix_band_klein.mtx"), mtx)
+    exe = os.path.join(BIN, "sparseBench-CRS-HIP")
+    out = subprocess.run([exe, "-c", str(mtx)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert "Writing matrix to" in out.stdout.decode()
+    bmx = tmp_path / "matrix_band_klein.bmx"
+    golden = open(os.path.join(ROOT, "tests", "golden", "ref", "matrix_band_klein.bmx"), "rb").read()
+    assert open(bmx, "rb").read() == golden
+    runs = []
+    for f in (mtx, bmx):
+        r = subprocess.run([exe, "-m", str(f)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        runs.append([ln for ln in r.stdout.decode().splitlines()
+                     if ln.startswith(("Initial Residual", "Iteration =", "Solution performed", "Difference"))])
+    assert runs[0] == runs[1] and any("Solution performed 3 iterations" in ln for ln in runs[0]), runs

@@ -105,3 +105,48 @@ def test_hpcg_sizes_of_the_scope_table():
     q = hostapi.Problem("generate", 64, 64, 64, fmt="scs", Cc=64, sigma=1, upload=False)
     assert q.nr == 262144 and q.nnzTrue == 6859000 and q.nChunks == 4096 and q.nElems == 6931200
     q.free()
+
+
+@pytest.mark.parametrize("name", ["matrix_band_klein", "test0", "test8"])
+def test_bmx_binary_files_match_the_reference_writer_and_reload(name, tmp_path, monkeypatch):
+    """.bmx (src/matrixBinfile.h:15-19): the product's writer is byte-identical to the reference's
+    (golden files written by the reference's own `-c`, tests/golden/make_golden.py); the reader
+    slices rows per rank like src/matrixBinfile.c:155-166; SB_BMX_FP64=1 round-trips fp64 bits"""
+    import shutil
+    mtx = tmp_path / (name + ".mtx")
+    shutil.copy(os.path.join(REFDATA, name + ".mtx"), mtx)
+    out = hostapi.convert_mtx_to_bmx(mtx)
+    golden = open(os.path.join(REFDATA, name + ".bmx"), "rb").read()
+    assert open(out, "rb").read() == golden
+    assert golden[:22] == b"# SparseBench DataFile" and golden[22:24] == b"\0\0"
+
+    ref = hostapi.Problem(str(mtx), fmt="crs", upload=False)
+    rp, (col, val) = np.array(ref.array("rowPtr")), ref.gm_entries()
+    # f32 file: columns exact, values rounded to float32 (the reference's FEntry)
+    p = hostapi.Problem(out, fmt="crs", upload=False)
+    c2, v2 = p.gm_entries()
+    assert np.array_equal(p.array("rowPtr"), rp) and np.array_equal(c2, col)
+    assert np.array_equal(v2, val.astype(np.float32).astype(np.float64))
+    assert np.all(p.rhs()[0] == 1.0)
+    p.free()
+    # every rank reads its own row slice; together they are the whole matrix
+    for size in (2, 3):
+        rows, cols, vals = 0, [], []
+        for rank in range(size):
+            start, rp2, c2, v2 = hostapi.read_bmx_slice(out, rank, size)
+            n = len(rp2) - 1
+            assert start == rows and n == ref.nr // size + (1 if ref.nr % size > rank else 0)
+            assert np.array_equal(rp2, rp[start:start + n + 1] - rp[start])
+            rows += n
+            cols.append(c2), vals.append(v2)
+        assert rows == ref.nr and np.array_equal(np.concatenate(cols), col)
+        assert np.array_equal(np.concatenate(vals), val.astype(np.float32).astype(np.float64))
+    # fp64 extension: bit-exact reload, header byte 23 = '8'
+    monkeypatch.setenv("SB_BMX_FP64", "1")
+    out64 = hostapi.convert_mtx_to_bmx(mtx)
+    raw = open(out64, "rb").read()
+    assert raw[23:24] == b"8" and len(raw) == 24 + 8 + 4 * (ref.nr + 1) + 16 * len(val)
+    p = hostapi.Problem(out64, fmt="crs", upload=False)
+    c3, v3 = p.gm_entries()
+    assert np.array_equal(c3, col) and np.array_equal(v3.view(np.uint64), val.view(np.uint64))
+    p.free(), ref.free()
