@@ -493,7 +493,8 @@ struct TileHdr {
   uint32_t exc[4][2]; // U chunks: exception lanes (lo, hi)
   uint32_t excStart;  // the tile's exception entries: first, count (contiguous over its U chunks)
   uint32_t excCount;
-  uint32_t pad_[2];
+  uint32_t tile;      // which tile this is: headers are stored interior tiles first (see below)
+  uint32_t pad_;
 };
 static_assert(sizeof(TileHdr) == 192, "TileHdr is 48 words");
 constexpr int PAT_STOP_LANE          = 48; // the lane that fetches the stop flag next to the header
@@ -577,8 +578,8 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
     const PatEntry* __restrict__ classDict, const PatEntry* __restrict__ rowPats,
     const PatEntry* __restrict__ excRows, const TileSeg* __restrict__ segs,
     const double* __restrict__ x, double* __restrict__ y, uint32_t nr, uint32_t nChunks,
-    uint32_t blocksPerXcd, uint32_t padCol, uint32_t dictEntries, uint32_t excLds,
-    double* __restrict__ dotPartials, const int* __restrict__ stop)
+    uint32_t firstHdr, uint32_t nHdrs, uint32_t blocksPerXcd, uint32_t padCol, uint32_t dictEntries,
+    uint32_t excLds, double* __restrict__ dotPartials, const int* __restrict__ stop)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[]; // [dict][exception entries + 8][window]
   PatEntry* sd = reinterpret_cast<PatEntry*>(lds);
@@ -586,17 +587,20 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   double* sx   = reinterpret_cast<double*>(se + excLds + 8u);
   constexpr int PF = 8; // code groups prefetched (32 columns); wider chunks stream the rest
   constexpr int WB = 12; // window entries per thread in the first pass
-  const uint32_t nTiles = (nChunks + 3u) >> 2;
-  const uint32_t tile0  = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
-  const uint32_t tile   = min(tile0, nTiles - 1u); // clamped: every load below is unconditional
+  // A launch covers headers [firstHdr, firstHdr + nHdrs).  Headers are stored with the tiles
+  // that touch no halo column first, so that on several ranks the interior part of the
+  // product can run while the halo is still in flight (one launch for each part).
+  const uint32_t tile0 = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
+  const uint32_t hidx  = firstHdr + min(tile0, nHdrs - 1u); // clamped: every load below is unconditional
   // round trip 1: ONE vector load brings the tile header (lanes 0..47) and the stop flag
   // (lane 48); fields are then read out of the lanes (v_readlane -> SGPRs)
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t* hp  = reinterpret_cast<const uint32_t*>(hdrs + tile);
+  const uint32_t* hp  = reinterpret_cast<const uint32_t*>(hdrs + hidx);
   const uint32_t hv   = *(lane < (uint32_t)PAT_STOP_LANE ? hp + lane : reinterpret_cast<const uint32_t*>(stop));
   auto field = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)hv, i); };
   const int stopped    = (int)field(PAT_STOP_LANE);
   const uint32_t wv    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t tile  = field(46);
   const uint32_t chunk = tile * 4u + wv;
   const uint32_t row   = chunk * 64u + lane;
   const bool active    = chunk < nChunks; // wave-uniform; inactive waves still help staging
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   asm volatile("" ::"v"(cw[0]), "v"(cw[1]), "v"(cw[2]), "v"(cw[3]), "v"(cw[4]), "v"(cw[5]), "v"(cw[6]),
                "v"(cw[7]), "v"(base), "v"(xrow), "v"(mine.v), "v"(mine.off8), "v"(mine.m));
   asm volatile("" ::"v"(ex0.v), "v"(ex0.off8), "v"(ex1.v), "v"(ex1.off8));
-  if (tile0 >= nTiles || stopped) return; // uniform per workgroup
+  if (tile0 >= nHdrs || stopped) return; // uniform per workgroup
   if (simple) {
     if (threadIdx.x == 0) sx[0] = xpad;
 #pragma unroll

@@ -102,6 +102,8 @@ struct Ctx {
   bool init = false;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr; // halo exchange while the interior tiles are multiplied
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
   hipDeviceProp_t prop;
   char name[320];
   // scratch for stand-alone ddot / permuted sb_spmv
@@ -194,6 +196,7 @@ struct sb_matrix {
   PatEntry* rowPats     = nullptr; // level 5: shared row patterns
   PatEntry* excRows     = nullptr; // level 5: expanded exception rows of the U chunks
   uint32_t patDict = 0, patExcLds = 0; // LDS layout of spmv_scs64_pat: table entries, exception entries
+  uint32_t patInterior = 0;            // headers [0, patInterior): tiles that touch no halo column
   uint32_t nRowPats = 0, nUniformChunks = 0;
   uint32_t nPatClasses  = 0;
   double patBytes       = 0.0;
@@ -266,6 +269,9 @@ void sb_init(int device)
   HIP_CHECK(hipGetDeviceProperties(&g.prop, device));
   snprintf(g.name, sizeof g.name, "%s (%s)", g.prop.name[0] ? g.prop.name : "AMD Instinct", g.prop.gcnArchName);
   HIP_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
+  HIP_CHECK(hipEventCreateWithFlags(&g.evFork, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&g.evJoin, hipEventDisableTiming));
   HIP_CHECK(hipMalloc(&g.scalar, 64));
   HIP_CHECK(hipMemset(g.scalar, 0, 64)); // [0] scratch double, [4] a permanent int 0 (zero_flag)
   g.device = device;
@@ -282,6 +288,9 @@ void sb_finalize(void)
     if (g.ws[i]) HIP_CHECK(hipFree(g.ws[i]));
   HIP_CHECK(hipFree(g.scalar));
   HIP_CHECK(hipStreamDestroy(g.stream));
+  HIP_CHECK(hipStreamDestroy(g.stream2));
+  HIP_CHECK(hipEventDestroy(g.evFork));
+  HIP_CHECK(hipEventDestroy(g.evJoin));
   g = Ctx();
 }
 
@@ -777,6 +786,7 @@ static void build_patterns(sb_matrix* m)
   for (uint32_t t = 0; t < nTiles; t++) {
     TileHdr& h = hdrs[t];
     memset(&h, 0, sizeof h);
+    h.tile = t;
     h.cls = tileClass[t], h.nseg = segPtr[t + 1] - segPtr[t], h.segPtr = segPtr[t], h.win = 1;
     h.excStart = tileExcStart[t], h.excCount = tileExcCount[t];
     for (uint32_t w = 0; w < 4; w++) {
@@ -803,13 +813,27 @@ static void build_patterns(sb_matrix* m)
     }
     h.flags = simple ? PAT_SIMPLE_WINDOW : 0u;
   }
+  // tiles whose window holds a halo column (>= nr) go last: the interior part of the product
+  // does not have to wait for the halo exchange (loop_body)
+  m->patInterior = nTiles;
+  if (m->nc > m->nr) {
+    auto touches_halo = [&](const TileHdr& h) {
+      for (uint32_t s2 = 0; s2 < h.nseg; s2++) {
+        const TileSeg& sg = segs[h.segPtr + s2];
+        if (sg.col + sg.len > m->nr) return true;
+      }
+      return false;
+    };
+    auto mid = std::stable_partition(hdrs.begin(), hdrs.end(), [&](const TileHdr& h) { return !touches_halo(h); });
+    m->patInterior = (uint32_t)(mid - hdrs.begin());
+  }
   m->tileHdrs = (TileHdr*)upload(hdrs.data(), hdrs.size() * sizeof(TileHdr));
   if (getenv("SB_PACK_REPORT")) {
     size_t nSimple = 0;
     for (const TileHdr& h : hdrs) nSimple += h.flags & PAT_SIMPLE_WINDOW;
-    fprintf(stderr, "sbhip pack: %u tiles (%zu simple windows, max %u entries), %u classes, %u/%u U chunks, "
+    fprintf(stderr, "sbhip pack: %u tiles (%u interior, %zu simple windows, max %u entries), %u classes, %u/%u U chunks, "
                     "%zu row patterns (%zu entries), %llu exception entries (max %u per tile), %llu code words\n",
-        nTiles, nSimple, m->ldsWindow, m->nPatClasses, m->nUniformChunks, m->nChunks, patIndex.size(),
+        nTiles, m->patInterior, nSimple, m->ldsWindow, m->nPatClasses, m->nUniformChunks, m->nChunks, patIndex.size(),
         rowPats.size(), (unsigned long long)excEntries, excLds, (unsigned long long)words);
   }
   m->patBytes = (double)words * 4.0 + 16.0 * (double)excEntries + 2.0 * 64.0 * m->nChunks + 16.0 * nSegs +
@@ -920,11 +944,19 @@ static int g_scs_nt     = -1;
 static int g_scs_xcd    = 1;
 
 // dotPartials != NULL: fuse the level-0 partials of p.Ap into the SpMV (SCS C=64 only)
+// part: 0 the whole product; 1 / 2 its interior / halo-touching tiles (spmv_can_split only)
+static bool spmv_can_split(const sb_matrix* m)
+{
+  return m->fmt == 1 && m->C == 64 && m->usePacked == 3 && m->patInterior > 0 &&
+         m->patInterior < (m->nChunks + 3) / 4;
+}
+
 static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* dotPartials,
-    const int* stop)
+    const int* stop, int part = 0)
 {
   const bool dot = dotPartials != nullptr;
   if (m->nr == 0) return;
+  if (part != 0 && !spmv_can_split(m)) SB_FATAL("this SpMV kernel cannot be launched in parts");
   if (m->fmt == 0) {
     if (dot) SB_FATAL("fused dot is an SCS C=64 feature");
     const uint32_t per = (m->nRowBlocks + 7) / 8;
@@ -945,14 +977,18 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
     if (m->usePacked == 3) {
       const size_t shmem = ((size_t)m->patDict + m->patExcLds + 8) * sizeof(PatEntry) + (size_t)m->ldsWindow * sizeof(double);
       if (!stop) stop = zero_flag();
+      const uint32_t first = part == 2 ? m->patInterior : 0u;
+      const uint32_t count = part == 1 ? m->patInterior : part == 2 ? nBlocks - m->patInterior : nBlocks;
+      const uint32_t pper  = g_scs_xcd ? (count + 7) / 8 : 0;
+      const dim3 pgrid(g_scs_xcd ? pper * 8 : count);
       if (dot)
-        hipLaunchKernelGGL((spmv_scs64_pat<true>), grid, block, shmem, g.stream, m->tileHdrs, m->jcodes,
-            m->rowBase, m->classDict, m->rowPats, m->excRows, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol,
-            m->patDict, m->patExcLds, dotPartials, stop);
+        hipLaunchKernelGGL((spmv_scs64_pat<true>), pgrid, block, shmem, g.stream, m->tileHdrs, m->jcodes,
+            m->rowBase, m->classDict, m->rowPats, m->excRows, m->tileSegs, x, y, m->nr, m->nChunks, first, count, pper,
+            m->padCol, m->patDict, m->patExcLds, dotPartials, stop);
       else
-        hipLaunchKernelGGL((spmv_scs64_pat<false>), grid, block, shmem, g.stream, m->tileHdrs, m->jcodes,
-            m->rowBase, m->classDict, m->rowPats, m->excRows, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol,
-            m->patDict, m->patExcLds, dotPartials, stop);
+        hipLaunchKernelGGL((spmv_scs64_pat<false>), pgrid, block, shmem, g.stream, m->tileHdrs, m->jcodes,
+            m->rowBase, m->classDict, m->rowPats, m->excRows, m->tileSegs, x, y, m->nr, m->nChunks, first, count, pper,
+            m->padCol, m->patDict, m->patExcLds, dotPartials, stop);
     } else if (m->usePacked == 2) {
       const size_t shmem = (256 + (size_t)m->ldsWindow) * sizeof(double);
 #define LDS_LAUNCH(DI, DO)                                                                                   \
@@ -1291,11 +1327,12 @@ void sb_halo_free(sb_halo* h)
   delete h;
 }
 
-static void halo_exchange(sb_halo* h, double* x, const int* stop)
+static void halo_exchange(sb_halo* h, double* x, const int* stop, hipStream_t stream = nullptr)
 {
   if (!h || g.size == 1) return;
+  if (!stream) stream = g.stream;
   if (h->totalSend) {
-    hipLaunchKernelGGL(gather_k, dim3(stream_grid(h->totalSend, 256)), dim3(256), 0, g.stream,
+    hipLaunchKernelGGL(gather_k, dim3(stream_grid(h->totalSend, 256)), dim3(256), 0, stream,
         (uint32_t)h->totalSend, h->packIdx, x, h->sendBuf, stop);
     HIP_CHECK(hipGetLastError());
   }
@@ -1303,7 +1340,7 @@ static void halo_exchange(sb_halo* h, double* x, const int* stop)
   // RCCL group of point-to-point transfers over xGMI, received straight into the
   // tail of x (no unpack), stream-ordered.
   if (g.hasXport) {
-    HIP_CHECK(hipStreamSynchronize(g.stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
     g.xport.neighbour_exchange(g.xport.ctx, h->sendBuf, h->outdegree, h->destinations.data(),
         h->sendCounts.data(), h->sdispls.data(), x + h->nr, h->indegree, h->sources.data(),
         h->recvCounts.data(), h->rdispls.data());
@@ -1312,10 +1349,10 @@ static void halo_exchange(sb_halo* h, double* x, const int* stop)
   RCCL_CHECK(rccl.GroupStart());
   for (int i = 0; i < h->outdegree; i++)
     RCCL_CHECK(rccl.Send(h->sendBuf + h->sdispls[i], (size_t)h->sendCounts[i], ncclFloat64_,
-        h->destinations[i], g.comm, g.stream));
+        h->destinations[i], g.comm, stream));
   for (int i = 0; i < h->indegree; i++)
     RCCL_CHECK(rccl.Recv(x + h->nr + h->rdispls[i], (size_t)h->recvCounts[i], ncclFloat64_,
-        h->sources[i], g.comm, g.stream));
+        h->sources[i], g.comm, stream));
   RCCL_CHECK(rccl.GroupEnd());
 }
 
@@ -1501,6 +1538,28 @@ static void loop_body(sb_cg* s, int k)
     mark(s, R_WAXPBY);
   }
   HIP_CHECK(hipGetLastError());
+  static const bool overlapHalo = !(getenv("SB_HALO_OVERLAP") && atoi(getenv("SB_HALO_OVERLAP")) == 0);
+  if (overlapHalo && multi_rank() && s->halo && spmv_can_fuse_dot(s) && spmv_can_split(s->A)) {
+    // :122-126 with the halo exchange hidden behind the interior tiles: the exchange (pack,
+    // send/recv into the tail of p) runs on a second stream while the tiles that touch no
+    // halo column are multiplied; the halo-touching tiles follow.  RCCL calls on the one
+    // communicator stay ordered: the exchange is complete (event) before anything later.
+    if (g.hasXport) halo_exchange(s->halo, s->p, stop); // host-mediated: synchronous anyway
+    else {
+      HIP_CHECK(hipEventRecord(g.evFork, g.stream));
+      HIP_CHECK(hipStreamWaitEvent(g.stream2, g.evFork, 0));
+      halo_exchange(s->halo, s->p, stop, g.stream2);
+      HIP_CHECK(hipEventRecord(g.evJoin, g.stream2));
+    }
+    mark(s, R_COMM);
+    spmv_event(s);
+    launch_spmv(s->A, s->p, s->Ap, s->partials, stop, 1);
+    if (!g.hasXport) HIP_CHECK(hipStreamWaitEvent(g.stream, g.evJoin, 0));
+    launch_spmv(s->A, s->p, s->Ap, s->partials, stop, 2);
+    spmv_event(s);
+    mark(s, R_SPMVM);
+    goto alpha_step;
+  }
   halo_exchange(s->halo, s->p, stop); // :122
   mark(s, R_COMM);
   spmv_event(s);
@@ -1514,6 +1573,7 @@ static void loop_body(sb_cg* s, int k)
     mark(s, R_SPMVM);
     launch_dot_spans(0, n, s->p, s->Ap, nullptr, nullptr, s->S, s->partials, stop);
   }
+alpha_step:
   scalar_launch<2>(s);
   mark(s, R_DDOT);
   if (s->fused) { // r -= alpha Ap (:128) + next r.r, beta, loop test; x += alpha p (:127) is owed

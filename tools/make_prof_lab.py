@@ -28,12 +28,12 @@ def patch(path, pairs):
 patch(W + "/sparsebench_amd/csrc/pack.hip.h", [
     ("template <bool DOT>\n__global__ __launch_bounds__(256) void spmv_scs64_pat(",
      "__device__ long long g_prof[8192 * 8];\n"
-     "#define PROF(i) do { if (((PROF_POINTS) >> (i)) & 1) if (threadIdx.x == 0 && tile0 < 8192) g_prof[tile0 * 8 + (i)] = wall_clock64(); } while (0)\n"
+     "#define PROF(i) do { if (((PROF_POINTS) >> (i)) & 1) if (threadIdx.x == 0 && blockIdx.x < 8192) g_prof[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)\n"
      "template <bool DOT>\n__global__ __launch_bounds__(256) void spmv_scs64_pat("),
-    ("  // round trip 1: ONE vector load brings the tile header", "  PROF(0);\n  // round trip 1: ONE vector load brings the tile header"),
+    ("  // A launch covers headers [firstHdr", "  PROF(0);\n  // A launch covers headers [firstHdr"),
     ("  const int stopped    = (int)field(PAT_STOP_LANE);\n", "  const int stopped    = (int)field(PAT_STOP_LANE);\n  PROF(1);\n"),
-    ("  if (tile0 >= nTiles || stopped) return; // uniform per workgroup\n",
-     "  if (tile0 >= nTiles || stopped) return; // uniform per workgroup\n  PROF(2);\n"),
+    ("  if (tile0 >= nHdrs || stopped) return; // uniform per workgroup\n",
+     "  if (tile0 >= nHdrs || stopped) return; // uniform per workgroup\n  PROF(2);\n"),
     ("mine.off8 + sxOff, mine.m };\n  __syncthreads();\n", "mine.off8 + sxOff, mine.m };\n  __syncthreads();\n  PROF(3);\n"
      "#ifdef LAB_EXIT_AFTER_BARRIER\n  if (row < nr) y[row] = xrow + (double)base + sx[lane] + se[lane].v;\n  return;\n#endif\n"),
     ("  if (row < nr) y[row] = acc;\n  if (DOT) {\n    double t2", "  PROF(4);\n  if (row < nr) y[row] = acc;\n  if (DOT) {\n    double t2"),
