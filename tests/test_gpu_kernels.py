@@ -326,3 +326,49 @@ def test_special_values_propagate_like_the_cpu(gpu):
     assert np.array_equal(got.view(np.uint64), exp.view(np.uint64))
     for v in (dx, dy, dw):
         v.free()
+
+
+def test_pattern_levels_randomised_shapes(gpu, monkeypatch):
+    """levels 4-5 on matrices that are regular enough to qualify but ragged everywhere else: random
+    subsets of a small offset set (many odd rows: mixed U and L chunks, exception staging), rows wider
+    than 32 columns (streamed code groups / pattern entries past the prefetch), duplicate columns, empty
+    rows, several far-apart offsets (> 6 window segments: the slot-by-slot staging and the segment
+    overflow list), sigma on and off.  Every kernel mode must give the oracle's bits."""
+    L = gpu
+    monkeypatch.setenv("SB_PACK_LDS", "1")  # the window heuristic would refuse most of these
+    rng = np.random.default_rng(31)
+    built = 0
+    for trial in range(10):
+        nr = int(rng.integers(300, 2600))
+        far = trial % 3 == 0
+        offs = np.array([-1500, -700, -260, 0, 300, 900, 1400] if far else [-70, -9, -2, -1, 0, 1, 2, 11])
+        vals = np.array([4.0, -1.0, -0.25])
+        common = rng.random(nr) < (0.85 if trial % 2 == 0 else 0.4)
+        rows, cols, data = [0], [], []
+        for i in range(nr):
+            if rng.random() < 0.02:
+                pick = np.array([], dtype=np.int64)  # empty row
+            elif common[i]:
+                pick = offs
+            elif trial >= 5 and rng.random() < 0.1:
+                pick = rng.choice(offs, size=int(rng.integers(33, 45)))  # wide row, duplicate columns
+            else:
+                pick = np.sort(rng.choice(offs, size=int(rng.integers(1, len(offs) + 1)), replace=False))
+            pick = pick[(i + pick >= 0) & (i + pick < nr)]  # offsets that leave the matrix are dropped
+            c = i + pick
+            cols.append(c)
+            data.append(np.where(pick == 0, vals[0], np.where(np.abs(pick) < 5, vals[1], vals[2])))
+            rows.append(rows[-1] + len(c))
+        rp = np.array(rows, dtype=np.uint32)
+        col = np.concatenate(cols).astype(np.uint32)
+        val = np.concatenate(data).astype(np.float64)
+        gm = po.GMatrix.from_csr(rp, col, val, nc=nr)
+        x = rng.standard_normal(nr)
+        for sg in (1, 256):
+            s = gm.to_scs(64, sg)
+            m = upload_scs(L, s)
+            built += L.sb_matrix_pattern_classes(m) > 0
+            got, exp = gpu_spmv(L, m, x, nr), gm.spmv(x)
+            assert np.array_equal(got.view(np.uint64), exp.view(np.uint64)), (trial, sg, L.sb_matrix_packed_mode(m))
+            L.sb_matrix_free(m)
+    assert built >= 12, built  # most of the 20 really reach the pattern levels
