@@ -141,9 +141,9 @@ def main():
     ap.add_argument("--C", type=int, default=64)
     ap.add_argument("--sigma", type=int, default=256)
     ap.add_argument("--graph", type=int, default=0)
-    ap.add_argument("--pack-mode", type=int, default=3,
+    ap.add_argument("--pack-mode", type=int, default=-1,
                     help="SpMV stream: 0 reference layout, 1 compressed, 2 compressed + LDS x-window, "
-                         "3 pattern codes + LDS x-window (default: best available)")
+                         "3 pattern codes / row patterns + LDS x-window (default -1: the library's choice)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
                     help="N > 1 data plane: rccl (production) or host (gloo-staged; lets N ranks share one GPU "
                          "to rehearse the multi-rank flow -- its numbers are not a benchmark)")
@@ -212,7 +212,9 @@ def main():
                                rank=rank, size=world)
     cg = hostapi.CG(prob, fused=True, graph=bool(args.graph))
     K, W = args.steps, args.warmup
-    mode = prob.use_packed(args.pack_mode) if args.fmt == "scs" else 0
+    mode = 0
+    if args.fmt == "scs":
+        mode = prob.use_packed(args.pack_mode) if args.pack_mode >= 0 else prob.pack_info()["mode"]
 
     def timed_pass(with_spmv_events):
         """exactly K loop bodies, in segments restarted from x0 = 0 outside the clock"""

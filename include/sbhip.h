@@ -88,7 +88,9 @@ int sb_matrix_pack_level(const sb_matrix* m);
  * (built when every tile's window fits; SB_PACK=2 stops at mode 1), 3 one-byte pattern
  * codes naming (value, window-slot delta) pairs + LDS window (built when every tile has
  * <= 255 distinct pairs; SB_PACK=3 stops at mode 2).  Clamped to what the matrix has;
- * default = the highest available.  All modes give bit-identical results. */
+ * default = the highest available, except that matrices of at most one round of resident
+ * workgroups (8 tiles of 256 rows per CU) default to mode 2, which is faster there.  All modes give
+ * bit-identical results. */
 void sb_matrix_use_packed(sb_matrix* m, int mode);
 int sb_matrix_packed_mode(const sb_matrix* m);
 uint32_t sb_matrix_lds_window(const sb_matrix* m); /* doubles per workgroup, 0 if not built */

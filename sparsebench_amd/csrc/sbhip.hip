@@ -838,7 +838,11 @@ static void build_patterns(sb_matrix* m)
   }
   m->patBytes = (double)words * 4.0 + 16.0 * (double)excEntries + 2.0 * 64.0 * m->nChunks + 16.0 * nSegs +
                 (double)sizeof(TileHdr) * nTiles + (anyL ? 4096.0 * classes.size() : 0.0) + 16.0 * rowPats.size();
-  m->usePacked = 3; // 3: pattern codes / row patterns + x window in LDS
+  // Default kernel: the pattern kernel once the matrix is more than one round of resident
+  // workgroups (8 per CU); below that everything is one dependent-latency chain and the
+  // level-3 kernel's is shorter (64^3: 46.7k vs 43.2k CG it/s; 96^3: 22.8k vs 26.3k).
+  // sb_matrix_use_packed(m, 3) selects it regardless.
+  m->usePacked = nTiles > (uint32_t)g.prop.multiProcessorCount * 8u ? 3 : 2;
 }
 
 sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, uint32_t nChunks,

@@ -26,11 +26,13 @@ def f(a):
     return np.array([float(v) for v in a])
 
 
-def run_gpu(filename, n, fmt, Cc, sigma, itermax, eps=0.0, fused=True, graph=False, pack_mode=None):
+def run_gpu(filename, n, fmt, Cc, sigma, itermax, eps=0.0, fused=True, graph=False, pack_mode=None, pack_try=None):
     nx, ny, nz = n if isinstance(n, tuple) else (n, n, n)
     p = hostapi.Problem(filename, nx, ny, nz, fmt=fmt, Cc=Cc, sigma=sigma)
     if pack_mode is not None:
         assert p.use_packed(pack_mode) == pack_mode
+    if pack_try is not None and fmt == "scs":
+        p.use_packed(pack_try)  # clamped to what the matrix has
     cg = hostapi.CG(p, fused=fused, graph=graph)
     k = cg.solve(itermax, eps)
     rr, pap = cg.history()
@@ -48,12 +50,13 @@ def test_history_bit_identical_to_oracle_same_dot_order(gpu, fmt, Cc, sigma, n):
     dims = n if isinstance(n, tuple) else (n, n, n)
     g = po.GMatrix.generate(*dims)
     o = po.cg(g, itermax=60, fmt=fmt, Cc=Cc, sigma=sigma, dot="tree", want_x=True)
-    for fused in (True, False):
-        r = run_gpu("generate", n, fmt, Cc, sigma, 60, fused=fused)
+    # default kernel choice (small matrices: level 3) and the highest level the matrix has
+    for fused, pack_try in ((True, None), (False, None), (True, 3), (False, 3)):
+        r = run_gpu("generate", n, fmt, Cc, sigma, 60, fused=fused, pack_try=pack_try)
         assert r["k"] == o["k"]
-        assert np.array_equal(r["rr"], o["rr"]), (fused, "rr")
-        assert np.array_equal(r["pAp"], o["pAp"]), (fused, "pAp")
-        assert np.array_equal(r["x"], o["x"][0]), (fused, "x")
+        assert np.array_equal(r["rr"], o["rr"]), (fused, pack_try, "rr")
+        assert np.array_equal(r["pAp"], o["pAp"]), (fused, pack_try, "pAp")
+        assert np.array_equal(r["x"], o["x"][0]), (fused, pack_try, "x")
         assert r["err"] == o["max_err"]
 
 

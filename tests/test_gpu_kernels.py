@@ -39,7 +39,8 @@ def gpu_spmv(L, m, x, nr):
     y = dy.get()
     if L.sb_matrix_pack_level(m) > 0:
         best = L.sb_matrix_packed_mode(m)
-        assert best == (3 if L.sb_matrix_pattern_classes(m) else 2 if L.sb_matrix_lds_window(m) else 1)
+        # (matrices of at most one round of resident workgroups default to mode 2 even when mode 3 exists)
+        assert best in ((2, 3) if L.sb_matrix_pattern_classes(m) else (2,) if L.sb_matrix_lds_window(m) else (1,))
         # reference stream / packed + cache gathers / packed + LDS window / pattern codes + LDS window
         for mode in (0, 1, 2, 3):
             L.sb_matrix_use_packed(m, mode)
@@ -196,7 +197,7 @@ def test_pattern_dictionary_mode(gpu, monkeypatch):
             uni = C.c_uint32(0)
             pats = L.sb_matrix_row_patterns(m, C.byref(uni))
             if must:
-                assert L.sb_matrix_pattern_classes(m) >= 1 and L.sb_matrix_packed_mode(m) == 3, (dims, sg)
+                assert L.sb_matrix_pattern_classes(m) >= 1 and L.sb_matrix_packed_mode(m) == 2, (dims, sg)  # small
                 L.sb_matrix_use_packed(m, 2)
                 lds_bytes = L.sb_matrix_stream_bytes(m)
                 L.sb_matrix_use_packed(m, 3)
@@ -242,6 +243,7 @@ def test_pattern_dictionary_mode(gpu, monkeypatch):
     for sg in (1, 128):
         s = gm.to_scs(64, sg)
         m = upload_scs(L, s)
+        L.sb_matrix_use_packed(m, 3)
         assert L.sb_matrix_pattern_classes(m) >= 1 and L.sb_matrix_packed_mode(m) == 3
         assert np.array_equal(gpu_spmv(L, m, x, nr).view(np.uint64), gm.spmv(x).view(np.uint64))
         L.sb_matrix_free(m)
