@@ -212,9 +212,8 @@ def main():
                                rank=rank, size=world)
     cg = hostapi.CG(prob, fused=True, graph=bool(args.graph))
     K, W = args.steps, args.warmup
-    mode = 0
-    if args.fmt == "scs":
-        mode = prob.use_packed(args.pack_mode) if args.pack_mode >= 0 else prob.pack_info()["mode"]
+    # SCS: 0..3; CRS: 0 native kernel, 3 through its private pattern mirror (if the matrix has one)
+    mode = prob.use_packed(args.pack_mode) if args.pack_mode >= 0 else prob.pack_info()["mode"]
 
     def timed_pass(with_spmv_events):
         """exactly K loop bodies, in segments restarted from x0 = 0 outside the clock"""
@@ -273,8 +272,8 @@ def main():
         nnz_true = prob.nnzTrue
         cg_bytes = 96.0 * prob.nr + spmv_bytes  # reference's unfused op list
         workload = "hpcg_27pt_%d^3_per_gpu_%s_C%d_sigma%d" % (n, args.fmt, args.C, args.sigma)
-        kernel = ("spmv_crs_stream" if args.fmt == "crs" else
-                  ["spmv_scs64", "spmv_scs64_packed", "spmv_scs64_lds", "spmv_scs64_pat"][mode])
+        native = "spmv_crs_stream" if args.fmt == "crs" else "spmv_scs64"
+        kernel = [native, "spmv_scs64_packed", "spmv_scs64_lds", "spmv_scs64_pat"][mode]
         traffic, traffic_src = pmc_traffic(workload, kernel) if world == 1 else (None, None)
         out = {
             "metric": "cg_iterations_per_s",
@@ -313,10 +312,10 @@ def main():
             t_ref, ref_ms, ref_n = ref_leg
             ref_us = 1e3 * ref_ms / max(ref_n, 1)
             out["roofline_reference_layout"] = {
-                "bound": "hbm", "kernel": "spmv_scs64", "achieved": spmv_bytes / (ref_us * 1e-6) / 1e9,
+                "bound": "hbm", "kernel": native, "achieved": spmv_bytes / (ref_us * 1e-6) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_bytes / (ref_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "avg_launch_us": ref_us, "launches_timed": ref_n,
-                "traffic": pmc_traffic(workload, "spmv_scs64")[0] if world == 1 else None,
+                "traffic": pmc_traffic(workload, native)[0] if world == 1 else None,
                 "cg_iterations_per_s": world * K / t_ref}
         out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -91,6 +91,8 @@ int sb_matrix_pack_level(const sb_matrix* m);
  * default = the highest available, except that matrices of at most one round of resident
  * workgroups (8 tiles of 256 rows per CU) default to mode 2, which is faster there.  All modes give
  * bit-identical results. */
+/* CRS matrices: 0 = native CRS kernel, 3 = product through a device-private Sell-64-1 pattern mirror whose
+ * padding is not added (exactly the CRS loop's sums); built when the matrix has repeating row patterns. */
 void sb_matrix_use_packed(sb_matrix* m, int mode);
 int sb_matrix_packed_mode(const sb_matrix* m);
 uint32_t sb_matrix_lds_window(const sb_matrix* m); /* doubles per workgroup, 0 if not built */

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void pat_compact_k(const PackMeta* __restrict_
       const uint32_t base8 = (uint32_t)rowBase[(size_t)chunk * 64 + lane] << 3;
       for (uint32_t j = 0; j < len; j++) {
         const PatEntry e = cd[(c[(size_t)(j >> 2) * 64] >> (8u * (j & 3u))) & 255u];
-        excRows[(size_t)off + (size_t)ix * len + j] = PatEntry{ e.v, base8 * e.m + e.off8, 0u };
+        excRows[(size_t)off + (size_t)ix * len + j] = PatEntry{ e.v, base8 * e.m + e.off8, e.m };
       }
     }
   } else {
@@ -572,7 +572,10 @@ __global__ __launch_bounds__(256) void pat_compact_k(const PackMeta* __restrict_
 // ALU: the header is decoded with scalar ops, the window is copied segment by segment (no
 // per-entry search), U chunks read no code stream, and their odd lanes get ready-made
 // (value, offset) entries from LDS instead of decoding codes.
-template <bool DOT>
+// SKIPPAD: padded elements are NOT added (the reference's Sell-C-sigma loop adds 0.0 * x[0]
+// for them, src/matrix-SCS.c:151-155 / :208-227; its CRS loop has no such elements,
+// src/matrix-CRS.c:46-65) -- the instantiation behind the CRS format's private mirror.
+template <bool DOT, bool SKIPPAD>
 __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict__ hdrs,
     const uint32_t* __restrict__ stream, const uint16_t* __restrict__ rowBase,
     const PatEntry* __restrict__ classDict, const PatEntry* __restrict__ rowPats,
@@ -706,11 +709,11 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   }
   // offsets become LDS byte addresses here (once per staged entry, not once per use)
   const uint32_t sxOff = (dictEntries + excLds + 8u) * (uint32_t)sizeof(PatEntry);
-  if (threadIdx.x < excCount) se[threadIdx.x] = PatEntry{ ex0.v, ex0.off8 + sxOff, 0u };
-  if (threadIdx.x + 256u < excCount) se[threadIdx.x + 256u] = PatEntry{ ex1.v, ex1.off8 + sxOff, 0u };
+  if (threadIdx.x < excCount) se[threadIdx.x] = PatEntry{ ex0.v, ex0.off8 + sxOff, ex0.m };
+  if (threadIdx.x + 256u < excCount) se[threadIdx.x + 256u] = PatEntry{ ex1.v, ex1.off8 + sxOff, ex1.m };
   for (uint32_t i = 512u + threadIdx.x; i < excCount; i += 256u) {
     const PatEntry e = excRows[(size_t)excStart + i];
-    se[i]            = PatEntry{ e.v, e.off8 + sxOff, 0u };
+    se[i]            = PatEntry{ e.v, e.off8 + sxOff, e.m };
   }
   if (dictEntries) sd[threadIdx.x] = PatEntry{ mine.v, mine.off8 + sxOff, mine.m };
   __syncthreads();
@@ -733,10 +736,11 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
     const bool nopad   = (lenf & PAT_NOPAD) != 0u; // wave-uniform: no padding in the dominant pattern
     auto upair = [&](uint32_t j0, const bool full, const bool np) {
       double v[8], xs[8];
-      uint32_t o[8];
+      uint32_t o[8], keep[8];
 #pragma unroll
       for (uint32_t q = 0; q < 8; q++) {
         const PatEntry e = rp[full ? j0 + q : min(j0 + q, len - 1u)]; // uniform address: s_load
+        keep[q]          = np ? 1u : e.m;
         // (pinned to scalar registers: otherwise the compiler merges this load with the odd
         //  lanes' LDS read below into ONE flat load through a selected generic pointer)
         const unsigned long long vb = __builtin_bit_cast(unsigned long long, e.v);
@@ -752,6 +756,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
           const PatEntry e = me[j0 + q]; // entries past the row's end belong to the next row / the slack
           v[q]             = e.v;
           o[q]             = e.off8;
+          if (SKIPPAD) keep[q] = e.m;
         }
       }
 #pragma unroll
@@ -760,15 +765,16 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
       for (uint32_t q = 0; q < 8; q++) {
         const double prod = v[q] * xs[q];
         const double sum  = acc + prod;
-        acc               = (full || j0 + q < len) ? sum : acc; // wave-uniform select
+        acc               = ((full || j0 + q < len) && (!SKIPPAD || keep[q] != 0u)) ? sum : acc;
       }
     };
     auto uquad = [&](uint32_t j0) { // a chunk's last 1..4 columns
       double v[4], xs[4];
-      uint32_t o[4];
+      uint32_t o[4], keep[4];
 #pragma unroll
       for (uint32_t q = 0; q < 4; q++) {
         const PatEntry e = rp[min(j0 + q, len - 1u)];
+        keep[q]          = e.m;
         const unsigned long long vb = __builtin_bit_cast(unsigned long long, e.v);
         const unsigned long long vs =
             (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vb) |
@@ -782,6 +788,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
           const PatEntry e = me[j0 + q];
           v[q]             = e.v;
           o[q]             = e.off8;
+          if (SKIPPAD) keep[q] = e.m;
         }
       }
 #pragma unroll
@@ -790,7 +797,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
       for (uint32_t q = 0; q < 4; q++) {
         const double prod = v[q] * xs[q];
         const double sum  = acc + prod;
-        acc               = (j0 + q < len) ? sum : acc; // wave-uniform select
+        acc               = (j0 + q < len && (!SKIPPAD || keep[q] != 0u)) ? sum : acc;
       }
     };
     uint32_t j0 = 0;
@@ -814,7 +821,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
       for (uint32_t q = 0; q < 4; q++) {
         const double prod = e[q].v * xs[q];
         const double sum  = acc + prod;
-        acc               = (full || j0 + q < len) ? sum : acc; // wave-uniform select
+        acc               = ((full || j0 + q < len) && (!SKIPPAD || e[q].m != 0u)) ? sum : acc;
       }
     };
     auto pick = [&](uint32_t cwv, uint32_t j0) {

@@ -197,6 +197,9 @@ struct sb_matrix {
   PatEntry* excRows     = nullptr; // level 5: expanded exception rows of the U chunks
   uint32_t patDict = 0, patExcLds = 0; // LDS layout of spmv_scs64_pat: table entries, exception entries
   uint32_t patInterior = 0;            // headers [0, patInterior): tiles that touch no halo column
+  // CRS: a private Sell-64-1 mirror carrying only the pattern levels (SKIPPAD kernel); usePacked
+  // 3 = product through the mirror, 0 = native CRS kernel
+  sb_matrix* mirror = nullptr;
   uint32_t nRowPats = 0, nUniformChunks = 0;
   uint32_t nPatClasses  = 0;
   double patBytes       = 0.0;
@@ -371,6 +374,8 @@ static void* upload(const void* host, size_t bytes)
   return d;
 }
 
+static void build_crs_mirror(sb_matrix* m, const uint32_t* rowPtr, const uint32_t* colInd, const double* val);
+
 sb_matrix* sb_crs_upload(uint32_t nr, uint32_t nc, const uint32_t* rowPtr, const uint32_t* colInd,
     const double* val)
 {
@@ -397,6 +402,7 @@ sb_matrix* sb_crs_upload(uint32_t nr, uint32_t nc, const uint32_t* rowPtr, const
   m->rowPtr     = (uint32_t*)upload(rowPtr, ((size_t)nr + 1) * sizeof(uint32_t));
   m->colInd     = (uint32_t*)upload(colInd, (size_t)m->nnz * sizeof(uint32_t));
   m->val        = (double*)upload(val, (size_t)m->nnz * sizeof(double));
+  build_crs_mirror(m, rowPtr, colInd, val);
   return m;
 }
 
@@ -895,6 +901,51 @@ sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, u
   return m;
 }
 
+// CRS: a device-private Sell-64-1 mirror that exists only for its pattern levels (pack.hip.h).
+// Row sums are taken left to right exactly as src/matrix-CRS.c:46-65 does; the SKIPPAD kernel
+// does not add the mirror's padding, so the result is the CRS loop's bit for bit.  Kept only
+// when the pattern levels could be built; the native CRS kernel stays selectable
+// (sb_matrix_use_packed(m, 0)) and is the default for small matrices.
+static void build_crs_mirror(sb_matrix* m, const uint32_t* rowPtr, const uint32_t* colInd, const double* val)
+{
+  const char* env = getenv("SB_PACK");
+  if ((env ? atoi(env) : 5) < 4 || m->nr == 0 || m->nnz == 0) return;
+  const uint32_t nr = m->nr, nChunks = (nr + 63) / 64;
+  std::vector<uint32_t> chunkLens(nChunks, 0), chunkPtr(nChunks + 1, 0);
+  for (uint32_t i = 0; i < nr; i++) chunkLens[i / 64] = std::max(chunkLens[i / 64], rowPtr[i + 1] - rowPtr[i]);
+  uint64_t total = 0;
+  for (uint32_t c = 0; c < nChunks; c++) {
+    chunkPtr[c] = (uint32_t)total;
+    total += (uint64_t)chunkLens[c] * 64;
+  }
+  if (total > 0xFFFFFFFFull) return;
+  chunkPtr[nChunks] = (uint32_t)total;
+  std::vector<uint32_t> scol(total, 0u);
+  std::vector<double> sval(total, 0.0);
+  for (uint32_t i = 0; i < nr; i++) {
+    const size_t at = (size_t)chunkPtr[i / 64] + (i % 64);
+    for (uint32_t j = rowPtr[i]; j < rowPtr[i + 1]; j++) {
+      unsigned long long bits;
+      memcpy(&bits, val + j, 8);
+      // padding is (column 0, +0.0): a stored +0.0 at column 0 would be indistinguishable from it
+      if (colInd[j] == 0 && bits == 0) return;
+      scol[at + (size_t)(j - rowPtr[i]) * 64] = colInd[j];
+      sval[at + (size_t)(j - rowPtr[i]) * 64] = val[j];
+    }
+  }
+  sb_matrix* mm = sb_scs_upload(nr, m->nc, 64, 1, nChunks, (uint32_t)total, chunkPtr.data(), chunkLens.data(),
+      scol.data(), sval.data(), nullptr, nullptr);
+  if (mm->nPatClasses == 0) { // no repeating patterns: the native kernel it is
+    sb_matrix_free(mm);
+    return;
+  }
+  // only the pattern levels are used (the other SCS kernels add the padding)
+  sb_free(mm->val), sb_free(mm->colInd), sb_free(mm->pidx), sb_free(mm->pcodes), sb_free(mm->pslots);
+  mm->val = nullptr, mm->colInd = nullptr, mm->pidx = nullptr, mm->pcodes = nullptr, mm->pslots = nullptr;
+  m->mirror    = mm;
+  m->usePacked = mm->usePacked == 3 ? 3 : 0; // the same size rule as for SCS matrices
+}
+
 void sb_matrix_free(sb_matrix* m)
 {
   if (!m) return;
@@ -903,6 +954,7 @@ void sb_matrix_free(sb_matrix* m)
   sb_free(m->pmeta), sb_free(m->pidx), sb_free(m->pcodes), sb_free(m->pdict);
   sb_free(m->tileSegPtr), sb_free(m->tileSegs), sb_free(m->pslots);
   sb_free(m->rowBase), sb_free(m->tileClass), sb_free(m->jcodes), sb_free(m->classDict), sb_free(m->tileHdrs), sb_free(m->rowPats), sb_free(m->excRows);
+  if (m->mirror) sb_matrix_free(m->mirror);
   delete m;
 }
 
@@ -910,21 +962,25 @@ int sb_matrix_pack_level(const sb_matrix* m) { return m->packLevel; }
 void sb_matrix_use_packed(sb_matrix* m, int mode)
 { // 0 reference-layout stream, 1 packed stream + gathers through the cache, 2 packed + LDS window,
   // 3 pattern codes + LDS window; a mode the matrix does not have falls to the next lower one
-  if (mode >= 3 && m->nPatClasses) m->usePacked = 3;
+  if (m->fmt == 0) m->usePacked = mode >= 3 && m->mirror ? 3 : 0;
+  else if (mode >= 3 && m->nPatClasses) m->usePacked = 3;
   else if (mode >= 2 && m->ldsWindow) m->usePacked = 2;
   else if (mode >= 1 && m->packLevel) m->usePacked = 1;
   else m->usePacked = 0;
 }
 int sb_matrix_packed_mode(const sb_matrix* m) { return m->usePacked; }
-uint32_t sb_matrix_lds_window(const sb_matrix* m) { return m->ldsWindow; }
-uint32_t sb_matrix_pattern_classes(const sb_matrix* m) { return m->nPatClasses; }
+// the matrix whose pattern levels serve m: m itself (SCS) or its private mirror (CRS)
+static const sb_matrix* pat_of(const sb_matrix* m) { return m->fmt == 0 && m->mirror ? m->mirror : m; }
+uint32_t sb_matrix_lds_window(const sb_matrix* m) { return pat_of(m)->ldsWindow; }
+uint32_t sb_matrix_pattern_classes(const sb_matrix* m) { return pat_of(m)->nPatClasses; }
 uint32_t sb_matrix_row_patterns(const sb_matrix* m, uint32_t* uniformChunks)
 {
-  if (uniformChunks) *uniformChunks = m->nUniformChunks;
-  return m->nRowPats;
+  if (uniformChunks) *uniformChunks = pat_of(m)->nUniformChunks;
+  return pat_of(m)->nRowPats;
 }
 double sb_matrix_stream_bytes(const sb_matrix* m)
 { // bytes the SELECTED SpMV kernel moves per launch (matrix stream + x once + y once)
+  if (m->fmt == 0 && m->usePacked == 3) return m->mirror->patBytes + 8.0 * m->mirror->nrPadded + 8.0 * m->nc;
   if (m->fmt == 1 && m->usePacked == 3) return m->patBytes + 8.0 * m->nrPadded + 8.0 * m->nc;
   if (m->fmt == 1 && m->usePacked == 2) return m->slotBytes + 8.0 * m->nrPadded + 8.0 * m->nc;
   if (m->fmt == 1 && m->usePacked) return m->packedBytes + 8.0 * m->nrPadded + 8.0 * m->nc;
@@ -949,11 +1005,17 @@ static int g_scs_xcd    = 1;
 
 // dotPartials != NULL: fuse the level-0 partials of p.Ap into the SpMV (SCS C=64 only)
 // part: 0 the whole product; 1 / 2 its interior / halo-touching tiles (spmv_can_split only)
+static bool spmv_uses_patterns(const sb_matrix* m)
+{
+  return m->usePacked == 3 && (m->fmt == 0 ? m->mirror != nullptr : m->C == 64);
+}
 static bool spmv_can_split(const sb_matrix* m)
 {
-  return m->fmt == 1 && m->C == 64 && m->usePacked == 3 && m->patInterior > 0 &&
-         m->patInterior < (m->nChunks + 3) / 4;
+  const sb_matrix* pm = pat_of(m);
+  return spmv_uses_patterns(m) && pm->patInterior > 0 && pm->patInterior < (pm->nChunks + 3) / 4;
 }
+static void launch_pat(const sb_matrix* pm, bool skipPad, const double* x, double* y, double* dotPartials,
+    const int* stop, int part);
 
 static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* dotPartials,
     const int* stop, int part = 0)
@@ -961,8 +1023,10 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
   const bool dot = dotPartials != nullptr;
   if (m->nr == 0) return;
   if (part != 0 && !spmv_can_split(m)) SB_FATAL("this SpMV kernel cannot be launched in parts");
-  if (m->fmt == 0) {
-    if (dot) SB_FATAL("fused dot is an SCS C=64 feature");
+  if (m->fmt == 0 && spmv_uses_patterns(m)) {
+    launch_pat(m->mirror, true, x, y, dotPartials, stop, part);
+  } else if (m->fmt == 0) {
+    if (dot) SB_FATAL("fused dot needs the pattern kernel (SCS C=64, or CRS through its mirror)");
     const uint32_t per = (m->nRowBlocks + 7) / 8;
     hipLaunchKernelGGL(spmv_crs_stream, dim3(per * 8), dim3(CRS_THREADS), 0, g.stream, m->rowBlocks,
         m->rowPtr, m->colInd, m->val, x, y, m->nRowBlocks, per, stop);
@@ -979,20 +1043,7 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
     const uint32_t per     = g_scs_xcd ? (nBlocks + 7) / 8 : 0;
     dim3 grid(g_scs_xcd ? per * 8 : nBlocks), block(256);
     if (m->usePacked == 3) {
-      const size_t shmem = ((size_t)m->patDict + m->patExcLds + 8) * sizeof(PatEntry) + (size_t)m->ldsWindow * sizeof(double);
-      if (!stop) stop = zero_flag();
-      const uint32_t first = part == 2 ? m->patInterior : 0u;
-      const uint32_t count = part == 1 ? m->patInterior : part == 2 ? nBlocks - m->patInterior : nBlocks;
-      const uint32_t pper  = g_scs_xcd ? (count + 7) / 8 : 0;
-      const dim3 pgrid(g_scs_xcd ? pper * 8 : count);
-      if (dot)
-        hipLaunchKernelGGL((spmv_scs64_pat<true>), pgrid, block, shmem, g.stream, m->tileHdrs, m->jcodes,
-            m->rowBase, m->classDict, m->rowPats, m->excRows, m->tileSegs, x, y, m->nr, m->nChunks, first, count, pper,
-            m->padCol, m->patDict, m->patExcLds, dotPartials, stop);
-      else
-        hipLaunchKernelGGL((spmv_scs64_pat<false>), pgrid, block, shmem, g.stream, m->tileHdrs, m->jcodes,
-            m->rowBase, m->classDict, m->rowPats, m->excRows, m->tileSegs, x, y, m->nr, m->nChunks, first, count, pper,
-            m->padCol, m->patDict, m->patExcLds, dotPartials, stop);
+      launch_pat(m, false, x, y, dotPartials, stop, part);
     } else if (m->usePacked == 2) {
       const size_t shmem = (256 + (size_t)m->ldsWindow) * sizeof(double);
 #define LDS_LAUNCH(DI, DO)                                                                                   \
@@ -1043,6 +1094,32 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
     hipLaunchKernelGGL(spmv_scs_generic, dim3((m->nrPadded + 255) / 256), dim3(256), 0, g.stream,
         m->chunkPtr, m->chunkLens, m->colInd, m->val, x, y, m->nr, m->nrPadded, m->C, stop);
   }
+  HIP_CHECK(hipGetLastError());
+}
+
+static void launch_pat(const sb_matrix* pm, bool skipPad, const double* x, double* y, double* dotPartials,
+    const int* stop, int part)
+{
+  const bool dot         = dotPartials != nullptr;
+  const uint32_t nBlocks = (pm->nChunks + 3) / 4;
+  const size_t shmem = ((size_t)pm->patDict + pm->patExcLds + 8) * sizeof(PatEntry) + (size_t)pm->ldsWindow * sizeof(double);
+  if (!stop) stop = zero_flag();
+  const uint32_t first = part == 2 ? pm->patInterior : 0u;
+  const uint32_t count = part == 1 ? pm->patInterior : part == 2 ? nBlocks - pm->patInterior : nBlocks;
+  const uint32_t pper  = g_scs_xcd ? (count + 7) / 8 : 0;
+  const dim3 pgrid(g_scs_xcd ? pper * 8 : count), block(256);
+#define PAT_LAUNCH(DO, SK)                                                                                       \
+  hipLaunchKernelGGL((spmv_scs64_pat<DO, SK>), pgrid, block, shmem, g.stream, pm->tileHdrs, pm->jcodes, pm->rowBase, \
+      pm->classDict, pm->rowPats, pm->excRows, pm->tileSegs, x, y, pm->nr, pm->nChunks, first, count, pper,      \
+      pm->padCol, pm->patDict, pm->patExcLds, dotPartials, stop)
+  if (skipPad) {
+    if (dot) PAT_LAUNCH(true, true);
+    else PAT_LAUNCH(false, true);
+  } else {
+    if (dot) PAT_LAUNCH(true, false);
+    else PAT_LAUNCH(false, false);
+  }
+#undef PAT_LAUNCH
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1488,7 +1565,10 @@ void sb_cg_counters(const sb_cg* s, int out[5])
   out[0] = h.stop, out[1] = h.stop_next, out[2] = h.iters, out[3] = h.n_rr, out[4] = h.n_pAp;
 }
 
-static bool spmv_can_fuse_dot(const sb_cg* s) { return s->fused && s->A->fmt == 1 && s->A->C == 64; }
+static bool spmv_can_fuse_dot(const sb_cg* s)
+{ // p.Ap partials in the SpMV epilogue: the wave-per-chunk kernels (SCS C=64, or CRS through its mirror)
+  return s->fused && (s->A->fmt == 1 ? s->A->C == 64 : spmv_uses_patterns(s->A));
+}
 
 // levels 1-2 of the reduction + the scalar step: one 1-workgroup launch after the producer
 // (several ranks: local sum -> RCCL all-reduce in place on the stream -> scalar step;

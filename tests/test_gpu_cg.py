@@ -31,8 +31,8 @@ def run_gpu(filename, n, fmt, Cc, sigma, itermax, eps=0.0, fused=True, graph=Fal
     p = hostapi.Problem(filename, nx, ny, nz, fmt=fmt, Cc=Cc, sigma=sigma)
     if pack_mode is not None:
         assert p.use_packed(pack_mode) == pack_mode
-    if pack_try is not None and fmt == "scs":
-        p.use_packed(pack_try)  # clamped to what the matrix has
+    if pack_try is not None:
+        p.use_packed(pack_try)  # clamped to what the matrix has (CRS: its pattern mirror, if any)
     cg = hostapi.CG(p, fused=fused, graph=graph)
     k = cg.solve(itermax, eps)
     rr, pap = cg.history()
@@ -138,8 +138,10 @@ def test_full_size_properties_128(gpu, golden_1rank):
     a = run_gpu("generate", n, "scs", 64, 1, 60)
     m = n - 2
     assert a["rr"][0] == m ** 3 + 600 * m ** 2 + 3072 * m + 3200
-    c = run_gpu("generate", n, "crs", 64, 1, 60)
+    c = run_gpu("generate", n, "crs", 64, 1, 60, pack_mode=0)  # native CRS kernel
     assert np.array_equal(a["rr"], c["rr"]) and np.array_equal(a["pAp"], c["pAp"])
+    c3 = run_gpu("generate", n, "crs", 64, 1, 60, pack_mode=3)  # CRS through its pattern mirror (the default here)
+    assert np.array_equal(c3["rr"], c["rr"]) and np.array_equal(c3["pAp"], c["pAp"]) and np.array_equal(c3["x"], c["x"])
     u = run_gpu("generate", n, "scs", 64, 1, 60, fused=False)
     assert np.array_equal(a["rr"], u["rr"]) and np.array_equal(a["x"], u["x"])
     s = run_gpu("generate", n, "scs", 64, 256, 60)

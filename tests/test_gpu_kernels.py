@@ -37,7 +37,21 @@ def gpu_spmv(L, m, x, nr):
     dx, dy = DeviceVector.from_host(x), DeviceVector(nr)
     L.sb_spmv(m, dx.ptr, dy.ptr)
     y = dy.get()
-    if L.sb_matrix_pack_level(m) > 0:
+    if L.sb_matrix_pack_level(m) == 0 and L.sb_matrix_pattern_classes(m) > 0:
+        # CRS with a private pattern mirror: native kernel (0) and mirror (3) must agree
+        best = L.sb_matrix_packed_mode(m)
+        assert best in (0, 3)
+        for mode in (0, 3):
+            L.sb_matrix_use_packed(m, mode)
+            assert L.sb_matrix_packed_mode(m) == mode
+            dy.set(np.full(nr, 7.0))
+            L.sb_spmv(m, dx.ptr, dy.ptr)
+            y2 = dy.get()
+            nan = np.isnan(y)
+            assert np.array_equal(nan, np.isnan(y2)), "CRS kernel mode %d: NaN rows differ" % mode
+            assert np.array_equal(y[~nan].view(np.uint64), y2[~nan].view(np.uint64)), "CRS kernel mode %d differs" % mode
+        L.sb_matrix_use_packed(m, best)
+    elif L.sb_matrix_pack_level(m) > 0:
         best = L.sb_matrix_packed_mode(m)
         # (matrices of at most one round of resident workgroups default to mode 2 even when mode 3 exists)
         assert best in ((2, 3) if L.sb_matrix_pattern_classes(m) else (2,) if L.sb_matrix_lds_window(m) else (1,))
@@ -374,3 +388,59 @@ def test_pattern_levels_randomised_shapes(gpu, monkeypatch):
             assert np.array_equal(got.view(np.uint64), exp.view(np.uint64)), (trial, sg, L.sb_matrix_packed_mode(m))
             L.sb_matrix_free(m)
     assert built >= 12, built  # most of the 20 really reach the pattern levels
+
+
+def test_crs_through_its_pattern_mirror(gpu, monkeypatch):
+    """CRS matrices with repeating row patterns get a device-private Sell-64-1 mirror whose padding is
+    NOT added (src/matrix-CRS.c:46-65 has no padding): same bits as the oracle's CRS loop, also where
+    the Sell-C-sigma semantics would differ (Inf / NaN in x[0], which SCS padding multiplies by 0)"""
+    L = gpu
+    rng = np.random.default_rng(37)
+    for dims in ((16, 16, 16), (128, 128, 2), (70, 3, 5), (9, 8, 7)):
+        g = po.GMatrix.generate(*dims)
+        m = upload_crs(L, g)
+        assert L.sb_matrix_pattern_classes(m) >= 1, dims
+        assert L.sb_matrix_packed_mode(m) == 0  # small: the native kernel is the default
+        x = rng.standard_normal(g.nc)
+        assert np.array_equal(gpu_spmv(L, m, x, g.nr).view(np.uint64), g.spmv(x).view(np.uint64))
+        x[0], x[g.nc // 2] = np.inf, np.nan
+        L.sb_matrix_use_packed(m, 3)
+        got, exp = gpu_spmv(L, m, x, g.nr), g.spmv(x)
+        assert np.isnan(exp).any() and not np.isnan(exp).all()
+        assert np.array_equal(np.isnan(got), np.isnan(exp))  # only the rows that really touch x[0] / the NaN
+        ok = ~np.isnan(exp)
+        assert np.array_equal(got[ok].view(np.uint64), exp[ok].view(np.uint64))
+        L.sb_matrix_free(m)
+    # ragged rows, an empty row, duplicate columns, -0.0 and explicit zeros away from column 0
+    nr = 700
+    offs = np.array([-9, -2, -1, 0, 1, 2, 11])
+    rows, cols, data = [0], [], []
+    for i in range(nr):
+        pick = offs if rng.random() < 0.8 else np.sort(rng.choice(offs, size=int(rng.integers(0, 7)), replace=False))
+        pick = pick[(i + pick >= 1) & (i + pick < nr)]  # column 0 stays unused
+        cols.append(i + pick)
+        data.append(np.where(pick == 0, 4.0, np.where(pick == 11, 0.0, np.where(pick == -9, -0.0, -1.0))))
+        rows.append(rows[-1] + len(pick))
+    gm = po.GMatrix.from_csr(np.array(rows, dtype=np.uint32), np.concatenate(cols).astype(np.uint32),
+                             np.concatenate(data), nc=nr)
+    monkeypatch.setenv("SB_PACK_LDS", "1")
+    m = upload_crs(L, gm)
+    assert L.sb_matrix_pattern_classes(m) >= 1
+    x = rng.standard_normal(nr)
+    x[5] = np.inf
+    got, exp = gpu_spmv(L, m, x, nr), gm.spmv(x)
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    assert np.array_equal(got[ok].view(np.uint64), exp[ok].view(np.uint64))
+    L.sb_matrix_free(m)
+    # a stored +0.0 at column 0 cannot be told from padding: no mirror, native kernel only
+    col0 = gm.col.copy()
+    val0 = gm.val.copy()
+    col0[3], val0[3] = 0, 0.0
+    gz = po.GMatrix.from_csr(np.array(rows, dtype=np.uint32), col0, val0, nc=nr)
+    m = upload_crs(L, gz)
+    assert L.sb_matrix_pattern_classes(m) == 0 and L.sb_matrix_packed_mode(m) == 0
+    got, exp = gpu_spmv(L, m, x, nr), gz.spmv(x)
+    ok = ~np.isnan(exp)
+    assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(got[ok].view(np.uint64), exp[ok].view(np.uint64))
+    L.sb_matrix_free(m)
