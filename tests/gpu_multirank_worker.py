@@ -39,9 +39,9 @@ def main():
     plans = po.Plans(locs)
     o = po.cg(locs, plans, itermax=itermax, fmt=fmt, Cc=Cc, sigma=sigma, dot="tree", rank_sum="tree", want_x=True)
     results = {}
-    for mode in ((3, 2, 1, 0) if fmt == "scs" and Cc == 64 else (0,)):
-        if fmt == "scs":
-            prob.use_packed(mode)
+    # every kernel the matrix has: SCS C=64 levels 0..3; CRS native (0) and through its pattern mirror (3)
+    for mode in ((3, 2, 1, 0) if fmt == "scs" and Cc == 64 else (3, 0) if fmt == "crs" else (0,)):
+        prob.use_packed(mode)  # clamped to what the matrix has
         for fused in (True, False):
             cg = hostapi.CG(prob, fused=fused)
             k = cg.solve(itermax, 0.0)
