@@ -148,6 +148,17 @@ typedef struct {
                              const int* sources, const int* recvCounts, const int* rdispls);
 } sb_transport;
 void sb_comm_init_transport(int rank, int size, const sb_transport* t);
+/* In-kernel all-reduce of the CG scalars over peer-mapped memory (one launch per dot instead of
+ * local reduce | ncclAllReduce | scalar step).  Every rank owns a small fine-grained buffer that
+ * its peers map through HIP IPC.  sb_comm_init does this by itself (the handles travel over RCCL).
+ * A launcher with its own transport calls sb_comm_p2p_handle on every rank, gathers the
+ * SB_P2P_HANDLE_BYTES of all ranks in rank order, and calls sb_comm_p2p_open (collective): peers are
+ * mapped, one exchange is tested, and the ranks agree over the transport; any failure on any rank
+ * leaves every rank on the transport's all-reduce.  SB_P2P=0 disables.  Returns 1 when enabled. */
+#define SB_P2P_HANDLE_BYTES 64
+int sb_comm_p2p_handle(unsigned char* handle_out);
+int sb_comm_p2p_open(const unsigned char* all_handles); /* NULL: this rank has no handle */
+int sb_comm_p2p_enabled(void);
 void sb_comm_finalize(void);
 int sb_comm_rank(void);
 int sb_comm_size(void);

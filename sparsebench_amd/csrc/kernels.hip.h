@@ -38,6 +38,7 @@ struct CgScalars {
   int itermax;
   int hist_cap;
   int x_pending;  // 1: x += alpha p of the last body is still owed (applied by the next p update)
+  int p2p_error;  // 1: a peer's contribution to an in-kernel all-reduce did not arrive in time
 };
 
 // ---- wave-level fixed-order reductions --------------------------------------
@@ -507,11 +508,88 @@ __global__ __launch_bounds__(1024) void reduce_final_k(uint32_t m, const double*
   if (threadIdx.x == 0) *out = total;
 }
 
+// =============================================================================
+// In-kernel all-reduce of ONE double over peer-mapped memory (several ranks).
+// A dot product on P ranks is: local reduce | all-reduce of 8 bytes | scalar step.  Through
+// RCCL that is three dependent launches (~25 us); here the scalar step's own workgroup does
+// the exchange: every rank owns a small FINE-GRAINED buffer that all peers have mapped (HIP
+// IPC, xGMI); thread r stores this rank's value and then the sequence number into peer r's
+// buffer (system-scope release), thread r then waits for rank r's pair in the own buffer
+// (system-scope acquire), and the P values are added pairwise in rank order -- the same tree
+// on every rank, so all ranks continue with identical bits.  Two slot sets, used alternately:
+// a rank cannot be two exchanges ahead of a peer, because each exchange waits for all.
+// The wait is bounded (wall clock); a timeout raises CgScalars::p2p_error and stops the loop.
+// =============================================================================
+constexpr int P2P_MAX = 16; // ranks per communicator this path supports (one node)
+struct P2PSlot {
+  unsigned long long bits; // the double
+  unsigned long long seq;
+};
+struct P2PView {
+  int rank, size;
+  P2PSlot* peer[P2P_MAX]; // peer[r]: rank r's buffer, P2PSlot[2][P2P_MAX], as mapped in this process
+};
+constexpr long long P2P_TIMEOUT_TICKS = 200000000ll; // 2 s of wall_clock64 (100 MHz)
+
+// every thread of the workgroup calls this with the same `mine`; returns the same sum in every thread
+__device__ __forceinline__ double p2p_allreduce_sum(const P2PView* pv, double mine, unsigned long long seq,
+    double* sh /* >= P2P_MAX doubles of LDS */, int* err)
+{
+  const int t = (int)threadIdx.x, P = pv->size;
+  const unsigned par = (unsigned)(seq & 1ull);
+  if (t < P) {
+    P2PSlot* dst = pv->peer[t] + par * P2P_MAX + pv->rank;
+    __hip_atomic_store(&dst->bits, (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED,
+        __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    P2PSlot* src       = pv->peer[pv->rank] + par * P2P_MAX + t;
+    const long long t0 = wall_clock64();
+    bool ok            = true;
+    while (__hip_atomic_load(&src->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) {
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    sh[t] = ok ? __longlong_as_double((long long)__hip_atomic_load(&src->bits, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM))
+               : 0.0;
+    if (!ok) atomicExch(err, 1);
+  }
+  __syncthreads();
+  // pairwise tree in rank order: ((v0+v1)+(v2+v3))+... (an odd tail moves up unchanged)
+  double v[P2P_MAX];
+#pragma unroll
+  for (int i = 0; i < P2P_MAX; i++) v[i] = i < P ? sh[i] : 0.0;
+  int n = P;
+  while (n > 1) {
+    const int h = n >> 1;
+#pragma unroll
+    for (int i = 0; i < P2P_MAX / 2; i++)
+      if (i < h) v[i] = v[2 * i] + v[2 * i + 1];
+    if (n & 1) v[h] = v[n - 1];
+    n = h + (n & 1);
+  }
+  __syncthreads();
+  return v[0];
+}
+
+__global__ __launch_bounds__(64) void p2p_selftest_k(const P2PView* pv, unsigned long long seq, double mine,
+    double* out, int* err)
+{
+  __shared__ double sh[P2P_MAX];
+  const double r = p2p_allreduce_sum(pv, mine, seq, sh, err);
+  if (threadIdx.x == 0) *out = r;
+}
+
 // CG scalar step as its own launch: the reference-shaped (unfused) path, and after the
-// all-reduce on several ranks (REDUCE = false: the sum is already in S->local).
+// all-reduce on several ranks (REDUCE = false: the sum is already in S->local).  With pv != NULL
+// the all-reduce happens right here (p2p_allreduce_sum) and the step follows in the same launch.
 template <int MODE, bool REDUCE>
 __global__ __launch_bounds__(1024) void cg_scalar_k(uint32_t m, const double* __restrict__ q,
-    CgScalars* S, double* __restrict__ rr_hist, double* __restrict__ pAp_hist, int to_local, int defer_x)
+    CgScalars* S, double* __restrict__ rr_hist, double* __restrict__ pAp_hist, int to_local, int defer_x,
+    const P2PView* pv, unsigned long long seq)
 {
   __shared__ double lds16[16];
   // This launch sits on the critical path of every iteration: do not serialise the flag's
@@ -525,6 +603,14 @@ __global__ __launch_bounds__(1024) void cg_scalar_k(uint32_t m, const double* __
     if (to_local) {
       if (threadIdx.x == 0) S->local = total;
       return;
+    }
+    if (pv) {
+      __syncthreads(); // lds16 is reused
+      total = p2p_allreduce_sum(pv, total, seq, lds16, &S->p2p_error);
+      if (S->p2p_error) { // uniform: written before the barriers inside
+        if (threadIdx.x == 0) S->stop = 1;
+        return;
+      }
     }
   } else {
     total = S->local;

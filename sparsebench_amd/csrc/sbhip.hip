@@ -117,6 +117,12 @@ struct Ctx {
   int rank = 0, size = 1;
   bool hasXport = false;
   sb_transport xport;
+  // in-kernel all-reduce over peer-mapped memory (kernels.hip.h: p2p_allreduce_sum)
+  P2PSlot* p2pBuf = nullptr;        // this rank's buffer (fine-grained device memory), P2PSlot[2][P2P_MAX]
+  void* p2pPeer[P2P_MAX] = {};      // peers' buffers as opened here (IPC); [rank] = p2pBuf
+  P2PView* p2pView = nullptr;       // device copy of the view
+  unsigned long long p2pSeq = 0;    // exchanges issued so far (identical on every rank)
+  bool p2pOn = false;
 } g;
 
 inline bool multi_rank() { return g.comm != nullptr || g.hasXport; }
@@ -1259,6 +1265,15 @@ void sb_comm_init(int rank, int size, const void* idbytes)
   ncclUniqueId id;
   memcpy(&id, idbytes, SB_UNIQUE_ID_BYTES);
   RCCL_CHECK(rccl.CommInitRank(&g.comm, size, id, rank));
+  if (size > 1) { // peer-mapped buffers for the in-kernel all-reduce; the handles travel over RCCL
+    unsigned char mine[SB_P2P_HANDLE_BYTES], all[SB_P2P_HANDLE_BYTES * P2P_MAX];
+    const int have = size <= P2P_MAX && sb_comm_p2p_handle(mine);
+    if (!have) memset(mine, 0, sizeof mine);
+    if (size <= P2P_MAX) {
+      sb_comm_allgather_bytes(mine, SB_P2P_HANDLE_BYTES, all);
+      sb_comm_p2p_open(have ? all : nullptr);
+    }
+  }
 }
 
 void sb_comm_init_transport(int rank, int size, const sb_transport* t)
@@ -1270,8 +1285,112 @@ void sb_comm_init_transport(int rank, int size, const sb_transport* t)
   g.rank = rank, g.size = size, g.xport = *t, g.hasXport = true;
 }
 
+// ---- in-kernel all-reduce over peer-mapped memory: set-up ---------------------------------
+static void p2p_release()
+{
+  for (int r = 0; r < P2P_MAX; r++) {
+    if (g.p2pPeer[r] && g.p2pPeer[r] != (void*)g.p2pBuf) (void)hipIpcCloseMemHandle(g.p2pPeer[r]);
+    g.p2pPeer[r] = nullptr;
+  }
+  if (g.p2pBuf) (void)hipFree(g.p2pBuf);
+  if (g.p2pView) (void)hipFree(g.p2pView);
+  g.p2pBuf = nullptr, g.p2pView = nullptr, g.p2pOn = false, g.p2pSeq = 0;
+}
+
+int sb_comm_p2p_handle(unsigned char* handle_out)
+{
+  need_init();
+  const char* env = getenv("SB_P2P");
+  if (env && atoi(env) == 0) return 0;
+  static_assert(sizeof(hipIpcMemHandle_t) <= SB_P2P_HANDLE_BYTES, "IPC handle size");
+  if (!g.p2pBuf) {
+    void* buf = nullptr; // fine-grained: coherent between GPUs while kernels are running
+    if (hipExtMallocWithFlags(&buf, 2 * P2P_MAX * sizeof(P2PSlot), hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    g.p2pBuf = (P2PSlot*)buf;
+    HIP_CHECK(hipMemset(g.p2pBuf, 0, 2 * P2P_MAX * sizeof(P2PSlot)));
+    HIP_CHECK(hipDeviceSynchronize());
+  }
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, g.p2pBuf) != hipSuccess) {
+    (void)hipGetLastError();
+    p2p_release();
+    return 0;
+  }
+  memset(handle_out, 0, SB_P2P_HANDLE_BYTES);
+  memcpy(handle_out, &h, sizeof h);
+  return 1;
+}
+
+int sb_comm_p2p_open(const unsigned char* all_handles)
+{
+  need_init();
+  if (!multi_rank()) return 0;
+  int ok = all_handles != nullptr && g.p2pBuf != nullptr && g.size <= P2P_MAX;
+  unsigned char zero[SB_P2P_HANDLE_BYTES] = { 0 };
+  for (int r = 0; ok && r < g.size; r++) {
+    const unsigned char* hb = all_handles + (size_t)r * SB_P2P_HANDLE_BYTES;
+    if (memcmp(hb, zero, SB_P2P_HANDLE_BYTES) == 0) ok = 0; // that rank has none
+    else if (r == g.rank) g.p2pPeer[r] = g.p2pBuf;
+    else {
+      hipIpcMemHandle_t h;
+      memcpy(&h, hb, sizeof h);
+      if (hipIpcOpenMemHandle(&g.p2pPeer[r], h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+        (void)hipGetLastError();
+        g.p2pPeer[r] = nullptr;
+        ok = 0;
+      }
+    }
+  }
+  // every rank must come to the same decision.  Round 1 (the established transport): did everybody
+  // map everybody?  Round 2: one in-kernel exchange, checked, and agreed on over the transport again.
+  double* d = (double*)sb_malloc(4 * sizeof(double));
+  auto agree = [&](int mine) {
+    const double v = mine ? 1.0 : 0.0;
+    sb_h2d(d, &v, sizeof v);
+    sb_comm_reduction(d, 1);
+    double sum = 0.0;
+    sb_d2h(&sum, d, sizeof sum);
+    return sum == (double)g.size;
+  };
+  bool on = agree(ok);
+  if (on) {
+    P2PView view;
+    memset(&view, 0, sizeof view);
+    view.rank = g.rank, view.size = g.size;
+    for (int r = 0; r < g.size; r++) view.peer[r] = (P2PSlot*)g.p2pPeer[r];
+    HIP_CHECK(hipMalloc(&g.p2pView, sizeof view));
+    HIP_CHECK(hipMemcpy(g.p2pView, &view, sizeof view, hipMemcpyHostToDevice));
+    int* err = (int*)(d + 2);
+    HIP_CHECK(hipMemset(d, 0, 4 * sizeof(double)));
+    hipLaunchKernelGGL(p2p_selftest_k, dim3(1), dim3(64), 0, g.stream, (const P2PView*)g.p2pView, ++g.p2pSeq,
+        (double)(g.rank + 1), d + 1, err);
+    HIP_CHECK(hipGetLastError());
+    double got = 0.0;
+    int e      = 0;
+    sb_d2h(&got, d + 1, sizeof got);
+    sb_d2h(&e, err, sizeof e);
+    on = agree(!e && got == 0.5 * g.size * (g.size + 1));
+  }
+  sb_free(d);
+  if (!on) p2p_release();
+  g.p2pOn = on;
+  if (getenv("SB_PACK_REPORT") || getenv("SB_P2P_REPORT"))
+    fprintf(stderr, "sbhip comm: rank %d/%d in-kernel all-reduce over peer-mapped memory: %s\n", g.rank, g.size,
+        on ? "on" : "off (RCCL / transport all-reduce)");
+  return on ? 1 : 0;
+}
+
+int sb_comm_p2p_enabled(void) { return g.p2pOn ? 1 : 0; }
+
 void sb_comm_finalize(void)
 {
+  if (g.init) {
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    p2p_release();
+  }
   g.hasXport = false;
   if (g.comm) {
     HIP_CHECK(hipStreamSynchronize(g.stream));
@@ -1575,15 +1694,21 @@ static bool spmv_can_fuse_dot(const sb_cg* s)
 // MPI_Allreduce of src/comm.c:659)
 template <int MODE> static void scalar_launch(sb_cg* s, int defer_x = 0)
 {
+  if (multi_rank() && g.p2pOn) { // local reduce, in-kernel all-reduce and scalar step in ONE launch
+    hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
+        s->S, s->rr_hist, s->pAp_hist, 0, defer_x, (const P2PView*)g.p2pView, ++g.p2pSeq);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
-      s->S, s->rr_hist, s->pAp_hist, multi_rank() ? 1 : 0, defer_x);
+      s->S, s->rr_hist, s->pAp_hist, multi_rank() ? 1 : 0, defer_x, (const P2PView*)nullptr, 0ull);
   HIP_CHECK(hipGetLastError());
   if (multi_rank()) {
     mark(s, R_DDOT);
     sb_comm_reduction(&s->S->local, 1);
     mark(s, R_COMM);
     hipLaunchKernelGGL((cg_scalar_k<MODE, false>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
-        s->S, s->rr_hist, s->pAp_hist, 0, defer_x);
+        s->S, s->rr_hist, s->pAp_hist, 0, defer_x, (const P2PView*)nullptr, 0ull);
     HIP_CHECK(hipGetLastError());
   }
 }
@@ -1755,6 +1880,9 @@ int sb_cg_finish(sb_cg* s)
   HIP_CHECK(hipStreamSynchronize(g.stream));
   CgScalars h;
   HIP_CHECK(hipMemcpy(&h, s->S, sizeof h, hipMemcpyDeviceToHost));
+  if (h.p2p_error)
+    SB_FATAL("rank %d: a peer's contribution to an in-kernel all-reduce did not arrive within 2 s "
+             "(SB_P2P=0 selects the RCCL all-reduce)", g.rank);
   if (s->timing) {
     for (double& v : s->region_ms) v = 0.0;
     for (size_t i = 1; i < s->evUsed; i++) {

@@ -90,4 +90,12 @@ def attach(L, H, dist, rank, size):
     cb3, cb4 = capi.ALLREDUCE_FN(allreduce), capi.EXCHANGE_FN(exchange)
     tr = capi.TransportS(None, cb3, cb4)
     L.sb_comm_init_transport(rank, size, C.byref(tr))
+    # in-kernel all-reduce over peer-mapped memory (include/sbhip.h): gather the IPC handles, open, self-test
+    mine = (C.c_ubyte * 64)()
+    have = L.sb_comm_p2p_handle(mine)
+    t = torch.tensor(list(mine) if have else [0] * 64, dtype=torch.uint8)
+    outs = [torch.zeros(64, dtype=torch.uint8) for _ in range(size)]
+    dist.all_gather(outs, t)
+    allh = (C.c_ubyte * (64 * size))(*torch.cat(outs).tolist())
+    L.sb_comm_p2p_open(allh if have else None)
     return (cb1, cb2, xchg, cb3, cb4, tr)

@@ -63,9 +63,11 @@ def main():
         live = ref / ref[0] >= 1e-20
         assert (np.abs(rr - ref) / ref)[live].max() <= 1e-12  # north_star tolerance vs the MPI reference
     dist.barrier()
+    p2p = L.sb_comm_p2p_enabled()
     prob.free()
     L.sb_comm_finalize()
     if rank == 0:
+        print("P2P_ENABLED", p2p, flush=True)
         print("GPU_MULTIRANK_OK", fmt, Cc, sigma, n, size, flush=True)
     dist.destroy_process_group()
 

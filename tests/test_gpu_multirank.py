@@ -29,8 +29,12 @@ def _free_port():
     ("crs", 64, 1, 16, 2, 100),
     ("scs", 4, 8, 8, 3, 40),        # generic-C kernel, odd rank count
 ])
-def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax):
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+@pytest.mark.parametrize("p2p", ["1", "0"])
+def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax, p2p):
+    """p2p=1: the dot all-reduces happen inside the scalar step over peer-mapped (IPC) memory when the
+    ranks' kernels really run concurrently on the one GPU (otherwise the self-test falls back, which the
+    worker reports); p2p=0: local reduce | transport all-reduce | scalar step.  Same bits either way."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", SB_P2P=p2p, SB_P2P_REPORT="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(size),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "gpu_multirank_worker.py"), fmt, str(Cc), str(sigma), str(n), str(itermax)]
@@ -38,3 +42,6 @@ def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax):
     text = out.stdout.decode()
     assert out.returncode == 0, text[-4000:]
     assert "GPU_MULTIRANK_OK %s %d %d %d %d" % (fmt, Cc, sigma, n, size) in text, text[-3000:]
+    if p2p == "0":
+        assert "P2P_ENABLED 0" in text
+    print([ln for ln in text.splitlines() if "P2P_ENABLED" in ln or "in-kernel all-reduce" in ln][:3])
