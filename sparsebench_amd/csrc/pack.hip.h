@@ -1,16 +1,20 @@
 // pack.hip.h -- device-private, LOSSLESS compression of the Sell-C-sigma (C = 64) stream.
 //
-// The matrix stream is 77 % of the bytes a CG iteration moves, and the kernel is
-// HBM-bound, so bytes are time.  Two general, automatically detected encodings:
+// The matrix stream is 77 % of the bytes a CG iteration moves, and the reference-layout kernel
+// is HBM-bound, so bytes are time.  Levels, each detected automatically at upload and each
+// falling back to the previous one when the matrix does not qualify (SB_PACK caps the level):
 //
-//   values   if the matrix holds <= 256 distinct fp64 bit patterns (stencils, graph
-//            Laplacians, ...): one byte per element indexing a dictionary held in LDS;
-//            otherwise the fp64 values are streamed as before;
-//   columns  per chunk, 16-bit offsets from the chunk's smallest column when the chunk's
-//            columns span < 65535 (banded / stencil / well-ordered matrices); chunks that
-//            do not qualify (e.g. rows touching halo columns) keep 32-bit indices.
+//   1  columns  per chunk, 16-bit offsets from the chunk's smallest column when the chunk's
+//               columns span < 65535 (banded / stencil / well-ordered matrices); chunks that
+//               do not qualify (e.g. rows touching halo columns) keep 32-bit indices;
+//   2  values   if the matrix holds <= 256 distinct fp64 bit patterns (stencils, graph
+//               Laplacians, ...): one byte per element indexing a dictionary held in LDS;
+//   3  windows  per tile (4 chunks = one workgroup) the x entries its rows touch are staged in
+//               LDS; the 16-bit column becomes a slot in that window (spmv_scs64_lds);
+//   4  patterns one byte per element names a (value, slot delta) pair of the tile's class;
+//   5  rows     a chunk = one shared dominant row pattern + its few odd lanes (spmv_scs64_pat).
 //
-// Elements are regrouped so that a lane fetches four consecutive columns of its row
+// Levels 1-2: elements are regrouped so that a lane fetches four consecutive columns of its row
 // with one load: 8 B (or 16 B wide) of indices + 4 B of codes per lane per group,
 // i.e. 512 B / 1 KiB / 256 B per wave-instruction.  The host-visible arrays keep the
 // reference layout (src/SCSMatrix.h); this is a private mirror built once at upload.
@@ -19,7 +23,8 @@
 //
 // Reference semantics of padding (column 0, value 0.0, src/matrix-SCS.c:146-155) are
 // kept: a padded element is encoded as the marker 0xFFFF and decodes to `padCol`
-// (column 0, renumbered like any other column when sigma > 1).
+// (column 0, renumbered like any other column when sigma > 1).  (The CRS format's mirror
+// uses the SKIPPAD instantiation of the level 4-5 kernel instead: CRS has no padding terms.)
 #pragma once
 #include "kernels.hip.h"
 
