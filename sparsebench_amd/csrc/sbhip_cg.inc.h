@@ -1,0 +1,421 @@
+// sbhip_cg.inc.h -- part of the single translation unit sbhip.hip (textual include, shares its
+// static context): the device-resident CG loop.
+// ===========================================================================
+// CG
+// ===========================================================================
+enum { R_WAXPBY = 0, R_SPMVM = 1, R_DDOT = 2, R_COMM = 3 };
+
+static void mark(sb_cg* s, int region)
+{ // region = the region that ENDS here (-1: start marker)
+  if (!s->timing) return;
+  if (s->evUsed == s->ev.size()) {
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreate(&e));
+    s->ev.push_back(e);
+    s->evRegion.push_back(-1);
+  }
+  s->evRegion[s->evUsed] = region;
+  HIP_CHECK(hipEventRecord(s->ev[s->evUsed], g.stream));
+  s->evUsed++;
+}
+
+sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host, const double* xexact_host)
+{
+  need_init();
+  sb_cg* s = new sb_cg();
+  s->A = m, s->halo = halo, s->nr = m->nr, s->nc = m->nc;
+  if (halo && halo->nr != m->nr) SB_FATAL("halo plan and matrix disagree on nr");
+  if (halo && m->nr + (uint32_t)halo->externalCount != m->nc) SB_FATAL("halo externalCount != nc-nr");
+  const size_t nb = (size_t)m->nr * sizeof(double);
+  s->r  = (double*)sb_malloc(nb);
+  s->Ap = (double*)sb_malloc(nb);
+  s->x  = (double*)sb_malloc(nb);
+  s->b  = (double*)sb_malloc(nb);
+  s->p  = (double*)sb_malloc((size_t)m->nc * sizeof(double)); // nc = nr + externals (src/CGSolver.c:70)
+  s->xexact = xexact_host ? (double*)sb_malloc(nb) : nullptr;
+  double* tmp = scratch_ws(0, m->nr);
+  sb_h2d(tmp, b_host, nb);
+  sb_permute(m, tmp, s->b);
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  if (xexact_host) {
+    sb_h2d(tmp, xexact_host, nb);
+    sb_permute(m, tmp, s->xexact);
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+  }
+  s->S         = (CgScalars*)sb_malloc(sizeof(CgScalars));
+  s->nPartials = (m->nr + 255) / 256;
+  // level-0 partials: 4 per 256 rows; the tail beyond the last chunk stays +0.0
+  s->partials = (double*)sb_malloc((4 * (size_t)s->nPartials + 4) * sizeof(double));
+  HIP_CHECK(hipMemsetAsync(s->partials, 0, (4 * (size_t)s->nPartials + 4) * sizeof(double), g.stream));
+  s->hist_cap  = 0;
+  s->rr_hist = s->pAp_hist = nullptr;
+  s->fused      = 1;
+  s->use_graph  = 0;
+  s->graphReady = false;
+  s->iterGraph  = nullptr;
+  s->timing     = false;
+  s->evUsed     = 0;
+  s->loop_ms    = 0.f;
+  s->spmvTiming = false;
+  s->spmvEvUsed = 0;
+  s->k_next     = 1;
+  s->started    = false;
+  HIP_CHECK(hipEventCreate(&s->evLoop0));
+  HIP_CHECK(hipEventCreate(&s->evLoop1));
+  for (double& v : s->region_ms) v = 0.0;
+  return s;
+}
+
+void sb_cg_free(sb_cg* s)
+{
+  if (!s) return;
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  if (s->iterGraph) HIP_CHECK(hipGraphExecDestroy(s->iterGraph));
+  for (hipEvent_t e : s->ev) HIP_CHECK(hipEventDestroy(e));
+  for (hipEvent_t e : s->spmvEv) HIP_CHECK(hipEventDestroy(e));
+  HIP_CHECK(hipEventDestroy(s->evLoop0));
+  HIP_CHECK(hipEventDestroy(s->evLoop1));
+  sb_free(s->r), sb_free(s->Ap), sb_free(s->x), sb_free(s->b), sb_free(s->p), sb_free(s->xexact);
+  sb_free(s->S), sb_free(s->partials), sb_free(s->rr_hist), sb_free(s->pAp_hist);
+  delete s;
+}
+
+static void drop_graph(sb_cg* s)
+{
+  if (s->iterGraph) HIP_CHECK(hipGraphExecDestroy(s->iterGraph));
+  s->iterGraph = nullptr, s->graphReady = false;
+}
+
+void sb_cg_set_fused(sb_cg* s, int fused)
+{
+  if (s->fused != fused) drop_graph(s);
+  s->fused = fused;
+}
+void sb_cg_set_graph(sb_cg* s, int use_graph) { s->use_graph = use_graph; }
+
+void sb_cg_spmv_timing(sb_cg* s, int on)
+{
+  s->spmvTiming = on != 0;
+  s->spmvEvUsed = 0;
+}
+
+double sb_cg_spmv_ms(sb_cg* s, int* launches)
+{ // sum of the event-bracketed SpMV launches since sb_cg_spmv_timing(s, 1)
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  double total = 0.0;
+  int n        = 0;
+  for (size_t i = 0; i + 1 < s->spmvEvUsed; i += 2) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, s->spmvEv[i], s->spmvEv[i + 1]));
+    total += ms;
+    n++;
+  }
+  if (launches) *launches = n;
+  return total;
+}
+
+void sb_cg_counters(const sb_cg* s, int out[5])
+{ // stop, stop_next, iters, n_rr, n_pAp of the device control block
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  CgScalars h;
+  HIP_CHECK(hipMemcpy(&h, s->S, sizeof h, hipMemcpyDeviceToHost));
+  out[0] = h.stop, out[1] = h.stop_next, out[2] = h.iters, out[3] = h.n_rr, out[4] = h.n_pAp;
+}
+
+static bool spmv_can_fuse_dot(const sb_cg* s)
+{ // p.Ap partials in the SpMV epilogue: the wave-per-chunk kernels (SCS C=64, or CRS through its mirror)
+  return s->fused && (s->A->fmt == 1 ? s->A->C == 64 : spmv_uses_patterns(s->A));
+}
+
+// levels 1-2 of the reduction + the scalar step: one 1-workgroup launch after the producer
+// (several ranks: local sum -> RCCL all-reduce in place on the stream -> scalar step;
+// MPI_Allreduce of src/comm.c:659)
+template <int MODE> static void scalar_launch(sb_cg* s, int defer_x = 0)
+{
+  if (multi_rank() && g.p2pOn) { // local reduce, in-kernel all-reduce and scalar step in ONE launch
+    hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
+        s->S, s->rr_hist, s->pAp_hist, 0, defer_x, (const P2PView*)g.p2pView, ++g.p2pSeq);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
+  hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
+      s->S, s->rr_hist, s->pAp_hist, multi_rank() ? 1 : 0, defer_x, (const P2PView*)nullptr, 0ull);
+  HIP_CHECK(hipGetLastError());
+  if (multi_rank()) {
+    mark(s, R_DDOT);
+    sb_comm_reduction(&s->S->local, 1);
+    mark(s, R_COMM);
+    hipLaunchKernelGGL((cg_scalar_k<MODE, false>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
+        s->S, s->rr_hist, s->pAp_hist, 0, defer_x, (const P2PView*)nullptr, 0ull);
+    HIP_CHECK(hipGetLastError());
+  }
+}
+
+static void spmv_event(sb_cg* s)
+{
+  if (!s->spmvTiming) return;
+  if (s->spmvEvUsed == s->spmvEv.size()) {
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreate(&e));
+    s->spmvEv.push_back(e);
+  }
+  HIP_CHECK(hipEventRecord(s->spmvEv[s->spmvEvUsed++], g.stream));
+}
+
+// one loop body of solveCG (src/CGSolver.c:108-128).  Fused path: the r.r partials of the
+// NEXT body come out of this body's x/r update, and its beta + loop test are taken right
+// after it, so a body is: p update | SpMV (+p.Ap partials) | alpha | x/r update (+r.r
+// partials) | beta, loop test.
+static void loop_body(sb_cg* s, int k)
+{
+  const uint32_t n = s->nr;
+  const int* stop  = &s->S->stop;
+  dim3 gridV(stream_grid(n / 2 + 1, 256)), blockV(256);
+  if (k == 1) {
+    if (n) hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, (double*)nullptr, s->S, 1); // p = r (:109)
+    mark(s, R_WAXPBY);
+  } else {
+    if (!s->fused) { // rtrans = r.r ; beta (:111-113)
+      launch_dot_spans(0, n, s->r, s->r, nullptr, nullptr, s->S, s->partials, stop);
+      scalar_launch<1>(s);
+      mark(s, R_DDOT);
+    }
+    if (n) // p = r + beta p (:114); fused path: also the x update owed by the previous body (:127)
+      hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, s->fused ? s->x : (double*)nullptr, s->S, 0);
+    mark(s, R_WAXPBY);
+  }
+  HIP_CHECK(hipGetLastError());
+  static const bool overlapHalo = !(getenv("SB_HALO_OVERLAP") && atoi(getenv("SB_HALO_OVERLAP")) == 0);
+  if (overlapHalo && multi_rank() && s->halo && spmv_can_fuse_dot(s) && spmv_can_split(s->A)) {
+    // :122-126 with the halo exchange hidden behind the interior tiles: the exchange (pack,
+    // send/recv into the tail of p) runs on a second stream while the tiles that touch no
+    // halo column are multiplied; the halo-touching tiles follow.  RCCL calls on the one
+    // communicator stay ordered: the exchange is complete (event) before anything later.
+    if (g.hasXport) halo_exchange(s->halo, s->p, stop); // host-mediated: synchronous anyway
+    else {
+      HIP_CHECK(hipEventRecord(g.evFork, g.stream));
+      HIP_CHECK(hipStreamWaitEvent(g.stream2, g.evFork, 0));
+      halo_exchange(s->halo, s->p, stop, g.stream2);
+      HIP_CHECK(hipEventRecord(g.evJoin, g.stream2));
+    }
+    mark(s, R_COMM);
+    spmv_event(s);
+    launch_spmv(s->A, s->p, s->Ap, s->partials, stop, 1);
+    if (!g.hasXport) HIP_CHECK(hipStreamWaitEvent(g.stream, g.evJoin, 0));
+    launch_spmv(s->A, s->p, s->Ap, s->partials, stop, 2);
+    spmv_event(s);
+    mark(s, R_SPMVM);
+    goto alpha_step;
+  }
+  halo_exchange(s->halo, s->p, stop); // :122
+  mark(s, R_COMM);
+  spmv_event(s);
+  if (spmv_can_fuse_dot(s)) { // Ap = A p, alpha = rtrans / p.Ap (:123-126)
+    launch_spmv(s->A, s->p, s->Ap, s->partials, stop);
+    spmv_event(s);
+    mark(s, R_SPMVM);
+  } else {
+    launch_spmv(s->A, s->p, s->Ap, nullptr, stop);
+    spmv_event(s);
+    mark(s, R_SPMVM);
+    launch_dot_spans(0, n, s->p, s->Ap, nullptr, nullptr, s->S, s->partials, stop);
+  }
+alpha_step:
+  scalar_launch<2>(s);
+  mark(s, R_DDOT);
+  if (s->fused) { // r -= alpha Ap (:128) + next r.r, beta, loop test; x += alpha p (:127) is owed
+    launch_dot_spans(3, n, s->p, s->Ap, s->x, s->r, s->S, s->partials, stop);
+    mark(s, R_WAXPBY);
+    scalar_launch<1>(s, 1);
+    mark(s, R_DDOT);
+  } else if (n) {
+    hipLaunchKernelGGL(waxpby_sdev_k, gridV, blockV, 0, g.stream, n, s->x, &s->S->alpha, s->p, s->x, stop);
+    hipLaunchKernelGGL(waxpby_sdev_k, gridV, blockV, 0, g.stream, n, s->r, &s->S->neg_alpha, s->Ap, s->r, stop);
+    HIP_CHECK(hipGetLastError());
+    mark(s, R_WAXPBY);
+  }
+}
+
+static void ensure_hist(sb_cg* s, int cap)
+{
+  if (cap <= s->hist_cap) return;
+  sb_free(s->rr_hist), sb_free(s->pAp_hist);
+  s->hist_cap = cap;
+  s->rr_hist  = (double*)sb_malloc((size_t)cap * sizeof(double));
+  s->pAp_hist = (double*)sb_malloc((size_t)cap * sizeof(double));
+  drop_graph(s); // captured pointers are stale
+}
+
+static void run_body_maybe_graph(sb_cg* s, int k)
+{ // k >= 2 bodies are iteration-invariant (k lives in the device control block)
+  if (k < 2 || !s->use_graph || multi_rank() || s->timing || s->spmvTiming) {
+    loop_body(s, k);
+    return;
+  }
+  if (!s->graphReady) {
+    hipGraph_t graph;
+    HIP_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+    loop_body(s, 2);
+    HIP_CHECK(hipStreamEndCapture(g.stream, &graph));
+    HIP_CHECK(hipGraphInstantiate(&s->iterGraph, graph, nullptr, nullptr, 0));
+    HIP_CHECK(hipGraphDestroy(graph));
+    s->graphReady = true;
+  }
+  HIP_CHECK(hipGraphLaunch(s->iterGraph, g.stream));
+}
+
+void sb_cg_start(sb_cg* s, int itermax, double eps)
+{
+  need_init();
+  const uint32_t n = s->nr;
+  ensure_hist(s, itermax + 2);
+  s->timing  = !s->fused; // the reference-shaped op list is the one that gets the region table
+  s->evUsed  = 0;
+  memset(&s->hostS, 0, sizeof s->hostS);
+  s->hostS.itermax  = itermax;
+  s->hostS.eps      = eps;
+  s->hostS.hist_cap = s->hist_cap;
+  HIP_CHECK(hipMemcpyAsync(s->S, &s->hostS, sizeof(CgScalars), hipMemcpyHostToDevice, g.stream));
+  HIP_CHECK(hipMemsetAsync(s->x, 0, (size_t)n * sizeof(double), g.stream)); // x0 = 0 (:28)
+  HIP_CHECK(hipMemsetAsync(s->p, 0, (size_t)s->nc * sizeof(double), g.stream));
+  mark(s, -1);
+  // prologue, src/CGSolver.c:94-100
+  launch_waxpby(n, 1.0, s->x, 0.0, s->x, s->p, nullptr);
+  mark(s, R_WAXPBY);
+  halo_exchange(s->halo, s->p, nullptr);
+  mark(s, R_COMM);
+  launch_spmv(s->A, s->p, s->Ap, nullptr, nullptr);
+  mark(s, R_SPMVM);
+  if (s->fused) {
+    launch_dot_spans(2, n, s->b, s->Ap, nullptr, s->r, s->S, s->partials, nullptr);
+    mark(s, R_WAXPBY);
+  } else {
+    launch_waxpby(n, 1.0, s->b, -1.0, s->Ap, s->r, nullptr);
+    mark(s, R_WAXPBY);
+    launch_dot_spans(0, n, s->r, s->r, nullptr, nullptr, s->S, s->partials, nullptr);
+  }
+  scalar_launch<0>(s);
+  mark(s, R_DDOT);
+  s->k_next  = 1;
+  s->started = true;
+}
+
+void sb_cg_run_iters(sb_cg* s, int iters)
+{
+  need_init();
+  if (!s->started) SB_FATAL("sb_cg_run_iters before sb_cg_start");
+  for (int i = 0; i < iters; i++) run_body_maybe_graph(s, s->k_next++);
+}
+
+int sb_cg_finish(sb_cg* s)
+{
+  need_init();
+  if (s->nr) { // the x update the last body left to "the next p update": nobody comes after it
+    hipLaunchKernelGGL(cg_x_finalize, dim3(stream_grid(s->nr, 256)), dim3(256), 0, g.stream, s->nr, s->x, s->p, s->S);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemsetAsync(&s->S->x_pending, 0, sizeof(int), g.stream));
+  }
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  CgScalars h;
+  HIP_CHECK(hipMemcpy(&h, s->S, sizeof h, hipMemcpyDeviceToHost));
+  if (h.p2p_error)
+    SB_FATAL("rank %d: a peer's contribution to an in-kernel all-reduce did not arrive within 2 s "
+             "(SB_P2P=0 selects the RCCL all-reduce)", g.rank);
+  if (s->timing) {
+    for (double& v : s->region_ms) v = 0.0;
+    for (size_t i = 1; i < s->evUsed; i++) {
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, s->ev[i - 1], s->ev[i]));
+      if (s->evRegion[i] >= 0) s->region_ms[s->evRegion[i]] += ms;
+    }
+  }
+  s->timing = false;
+  return h.iters + 1; // the value of k when the reference's for loop exits (:107,:140)
+}
+
+int sb_cg_solve(sb_cg* s, int itermax, double eps)
+{
+  sb_cg_start(s, itermax, eps);
+  HIP_CHECK(hipEventRecord(s->evLoop0, g.stream));
+  sb_cg_run_iters(s, itermax > 1 ? itermax - 1 : 0);
+  HIP_CHECK(hipEventRecord(s->evLoop1, g.stream));
+  const int k = sb_cg_finish(s);
+  HIP_CHECK(hipEventElapsedTime(&s->loop_ms, s->evLoop0, s->evLoop1));
+  return k;
+}
+
+int sb_cg_history(const sb_cg* s, double* rr_out, int rr_cap, double* pAp_out, int pAp_cap, int* n_pAp)
+{
+  need_init();
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  CgScalars h;
+  HIP_CHECK(hipMemcpy(&h, s->S, sizeof h, hipMemcpyDeviceToHost));
+  int nrr = h.n_rr < s->hist_cap ? h.n_rr : s->hist_cap;
+  int npa = h.n_pAp < s->hist_cap ? h.n_pAp : s->hist_cap;
+  if (nrr > rr_cap) nrr = rr_cap;
+  if (npa > pAp_cap) npa = pAp_cap;
+  if (nrr > 0) HIP_CHECK(hipMemcpy(rr_out, s->rr_hist, (size_t)nrr * sizeof(double), hipMemcpyDeviceToHost));
+  if (npa > 0) HIP_CHECK(hipMemcpy(pAp_out, s->pAp_hist, (size_t)npa * sizeof(double), hipMemcpyDeviceToHost));
+  if (n_pAp) *n_pAp = npa;
+  return nrr;
+}
+
+void sb_cg_solution(const sb_cg* s, double* x_host)
+{
+  need_init();
+  double* tmp = scratch_ws(1, s->nr);
+  sb_unpermute(s->A, s->x, tmp);
+  sb_d2h(x_host, tmp, (size_t)s->nr * sizeof(double));
+}
+
+double sb_cg_check_residual(const sb_cg* s)
+{
+  need_init();
+  if (!s->xexact || s->nr == 0) return 0.0;
+  const uint32_t blocks = stream_grid(s->nr, 256);
+  double* q             = scratch_partials(blocks);
+  hipLaunchKernelGGL(max_abs_diff_partials, dim3(blocks), dim3(256), 0, g.stream, s->nr, s->x, s->xexact, q);
+  HIP_CHECK(hipGetLastError());
+  std::vector<double> h(blocks);
+  sb_d2h(h.data(), q, blocks * sizeof(double));
+  double m = 0.0;
+  for (double v : h)
+    if (v > m) m = v;
+  if (multi_rank()) { // commReduction(&residual, MAX), src/CGSolver.c:55
+    sb_h2d(g.scalar, &m, sizeof m);
+    sb_comm_reduction(g.scalar, 0);
+    sb_d2h(&m, g.scalar, sizeof m);
+  }
+  return m;
+}
+
+double sb_debug_stream_read_gbs(size_t bytes, int reps)
+{ // raw read ceiling of this device: `reps` passes over a `bytes`-sized buffer
+  need_init();
+  double2* buf = nullptr;
+  HIP_CHECK(hipMalloc(&buf, bytes));
+  HIP_CHECK(hipMemsetAsync(buf, 0, bytes, g.stream));
+  const size_t n2 = bytes / sizeof(double2);
+  dim3 grid((unsigned)g.prop.multiProcessorCount * 8), block(256);
+  hipLaunchKernelGGL(stream_read_k, grid, block, 0, g.stream, buf, n2, g.scalar);
+  hipEvent_t a, b;
+  HIP_CHECK(hipEventCreate(&a));
+  HIP_CHECK(hipEventCreate(&b));
+  HIP_CHECK(hipEventRecord(a, g.stream));
+  for (int r = 0; r < reps; r++) hipLaunchKernelGGL(stream_read_k, grid, block, 0, g.stream, buf, n2, g.scalar);
+  HIP_CHECK(hipEventRecord(b, g.stream));
+  HIP_CHECK(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+  HIP_CHECK(hipEventDestroy(a));
+  HIP_CHECK(hipEventDestroy(b));
+  HIP_CHECK(hipFree(buf));
+  return (double)bytes * reps / (ms * 1e-3) / 1e9;
+}
+
+double sb_cg_loop_ms(const sb_cg* s) { return (double)s->loop_ms; }
+
+void sb_cg_region_ms(const sb_cg* s, double out[4])
+{
+  for (int i = 0; i < 4; i++) out[i] = s->region_ms[i];
+}

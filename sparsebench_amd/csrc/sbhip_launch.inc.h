@@ -1,0 +1,239 @@
+// sbhip_launch.inc.h -- part of the single translation unit sbhip.hip (textual include, shares its
+// static context): kernel launches: SpMV (all formats / modes), waxpby, dots, permutation helpers.
+// ===========================================================================
+// kernels
+// ===========================================================================
+static int g_scs_unroll = -1;
+static int g_scs_nt     = -1;
+static int g_scs_xcd    = 1;
+
+// dotPartials != NULL: fuse the level-0 partials of p.Ap into the SpMV (SCS C=64 only)
+// part: 0 the whole product; 1 / 2 its interior / halo-touching tiles (spmv_can_split only)
+static bool spmv_uses_patterns(const sb_matrix* m)
+{
+  return m->usePacked == 3 && (m->fmt == 0 ? m->mirror != nullptr : m->C == 64);
+}
+static bool spmv_can_split(const sb_matrix* m)
+{
+  const sb_matrix* pm = pat_of(m);
+  return spmv_uses_patterns(m) && pm->patInterior > 0 && pm->patInterior < (pm->nChunks + 3) / 4;
+}
+static void launch_pat(const sb_matrix* pm, bool skipPad, const double* x, double* y, double* dotPartials,
+    const int* stop, int part);
+
+static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* dotPartials,
+    const int* stop, int part = 0)
+{
+  const bool dot = dotPartials != nullptr;
+  if (m->nr == 0) return;
+  if (part != 0 && !spmv_can_split(m)) SB_FATAL("this SpMV kernel cannot be launched in parts");
+  if (m->fmt == 0 && spmv_uses_patterns(m)) {
+    launch_pat(m->mirror, true, x, y, dotPartials, stop, part);
+  } else if (m->fmt == 0) {
+    if (dot) SB_FATAL("fused dot needs the pattern kernel (SCS C=64, or CRS through its mirror)");
+    const uint32_t per = (m->nRowBlocks + 7) / 8;
+    hipLaunchKernelGGL(spmv_crs_stream, dim3(per * 8), dim3(CRS_THREADS), 0, g.stream, m->rowBlocks,
+        m->rowPtr, m->colInd, m->val, x, y, m->nRowBlocks, per, stop);
+  } else if (m->C == 64) {
+    if (g_scs_unroll < 0) {
+      const char* u = getenv("SB_SCS_UNROLL");
+      g_scs_unroll  = u ? atoi(u) : 4;
+      const char* n = getenv("SB_SCS_NT");
+      g_scs_nt      = n ? atoi(n) : 1;
+      const char* xc = getenv("SB_SCS_XCD");
+      g_scs_xcd     = xc ? atoi(xc) : 1;
+    }
+    const uint32_t nBlocks = (m->nChunks + 3) / 4;
+    const uint32_t per     = g_scs_xcd ? (nBlocks + 7) / 8 : 0;
+    dim3 grid(g_scs_xcd ? per * 8 : nBlocks), block(256);
+    if (m->usePacked == 3) {
+      launch_pat(m, false, x, y, dotPartials, stop, part);
+    } else if (m->usePacked == 2) {
+      const size_t shmem = (256 + (size_t)m->ldsWindow) * sizeof(double);
+#define LDS_LAUNCH(DI, DO)                                                                                   \
+  hipLaunchKernelGGL((spmv_scs64_lds<DI, DO>), grid, block, shmem, g.stream, m->pmeta, m->pslots, m->pcodes, \
+      m->pdict, m->chunkPtr, m->val, m->tileSegPtr, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol,    \
+      dotPartials, stop)
+      if (m->nDict > 0) {
+        if (dot) LDS_LAUNCH(true, true);
+        else LDS_LAUNCH(true, false);
+      } else {
+        if (dot) LDS_LAUNCH(false, true);
+        else LDS_LAUNCH(false, false);
+      }
+#undef LDS_LAUNCH
+    } else if (m->usePacked == 1) {
+#define PK_LAUNCH(DI, DO)                                                                                 \
+  hipLaunchKernelGGL((spmv_scs64_packed<DI, DO>), grid, block, 0, g.stream, m->pmeta, m->pidx, m->pcodes, \
+      m->pdict, m->chunkPtr, m->val, x, y, m->nr, m->nChunks, per, m->padCol, dotPartials, stop)
+      if (m->nDict > 0) {
+        if (dot) PK_LAUNCH(true, true);
+        else PK_LAUNCH(true, false);
+      } else {
+        if (dot) PK_LAUNCH(false, true);
+        else PK_LAUNCH(false, false);
+      }
+#undef PK_LAUNCH
+    } else {
+#define SCS_LAUNCH(U, D, N)                                                                      \
+  hipLaunchKernelGGL((spmv_scs64<U, D, N>), grid, block, 0, g.stream, m->chunkPtr, m->chunkLens, \
+      m->colInd, m->val, x, y, m->nr, m->nChunks, per, dotPartials, stop)
+#define SCS_PICK(U)                                                                           \
+  do {                                                                                        \
+    if (dot) { if (g_scs_nt) SCS_LAUNCH(U, true, true); else SCS_LAUNCH(U, true, false); }    \
+    else { if (g_scs_nt) SCS_LAUNCH(U, false, true); else SCS_LAUNCH(U, false, false); }      \
+  } while (0)
+      switch (g_scs_unroll) {
+      case 1: SCS_PICK(1); break;
+      case 2: SCS_PICK(2); break;
+      case 8: SCS_PICK(8); break;
+      case 9: SCS_PICK(9); break;
+      default: SCS_PICK(4); break;
+      }
+#undef SCS_PICK
+#undef SCS_LAUNCH
+    }
+  } else {
+    if (dot) SB_FATAL("fused dot is an SCS C=64 feature");
+    hipLaunchKernelGGL(spmv_scs_generic, dim3((m->nrPadded + 255) / 256), dim3(256), 0, g.stream,
+        m->chunkPtr, m->chunkLens, m->colInd, m->val, x, y, m->nr, m->nrPadded, m->C, stop);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+static void launch_pat(const sb_matrix* pm, bool skipPad, const double* x, double* y, double* dotPartials,
+    const int* stop, int part)
+{
+  const bool dot         = dotPartials != nullptr;
+  const uint32_t nBlocks = (pm->nChunks + 3) / 4;
+  const size_t shmem = ((size_t)pm->patDict + pm->patExcLds + 8) * sizeof(PatEntry) + (size_t)pm->ldsWindow * sizeof(double);
+  if (!stop) stop = zero_flag();
+  const uint32_t first = part == 2 ? pm->patInterior : 0u;
+  const uint32_t count = part == 1 ? pm->patInterior : part == 2 ? nBlocks - pm->patInterior : nBlocks;
+  const uint32_t pper  = g_scs_xcd ? (count + 7) / 8 : 0;
+  const dim3 pgrid(g_scs_xcd ? pper * 8 : count), block(256);
+#define PAT_LAUNCH(DO, SK)                                                                                       \
+  hipLaunchKernelGGL((spmv_scs64_pat<DO, SK>), pgrid, block, shmem, g.stream, pm->tileHdrs, pm->jcodes, pm->rowBase, \
+      pm->classDict, pm->rowPats, pm->excRows, pm->tileSegs, x, y, pm->nr, pm->nChunks, first, count, pper,      \
+      pm->padCol, pm->patDict, pm->patExcLds, dotPartials, stop)
+  if (skipPad) {
+    if (dot) PAT_LAUNCH(true, true);
+    else PAT_LAUNCH(false, true);
+  } else {
+    if (dot) PAT_LAUNCH(true, false);
+    else PAT_LAUNCH(false, false);
+  }
+#undef PAT_LAUNCH
+  HIP_CHECK(hipGetLastError());
+}
+
+void sb_spmv_native(const sb_matrix* m, const double* x, double* y)
+{
+  need_init();
+  launch_spmv(m, x, y, nullptr, nullptr);
+}
+
+void sb_permute(const sb_matrix* m, const double* in_orig, double* out_perm)
+{
+  need_init();
+  if (!m->permuted) {
+    if (in_orig != out_perm) sb_d2d(out_perm, in_orig, (size_t)m->nr * sizeof(double));
+    return;
+  }
+  hipLaunchKernelGGL(gather_k, dim3(stream_grid(m->nr, 256)), dim3(256), 0, g.stream, m->nr,
+      m->newToOld, in_orig, out_perm, (const int*)nullptr);
+  HIP_CHECK(hipGetLastError());
+}
+
+void sb_unpermute(const sb_matrix* m, const double* in_perm, double* out_orig)
+{
+  need_init();
+  if (!m->permuted) {
+    if (in_perm != out_orig) sb_d2d(out_orig, in_perm, (size_t)m->nr * sizeof(double));
+    return;
+  }
+  hipLaunchKernelGGL(gather_k, dim3(stream_grid(m->nr, 256)), dim3(256), 0, g.stream, m->nr,
+      m->oldToNew, in_perm, out_orig, (const int*)nullptr);
+  HIP_CHECK(hipGetLastError());
+}
+
+void sb_spmv(const sb_matrix* m, const double* x, double* y)
+{
+  need_init();
+  if (!m->permuted) {
+    launch_spmv(m, x, y, nullptr, nullptr);
+    return;
+  }
+  double* xp = scratch_ws(0, m->nc);
+  double* yp = scratch_ws(1, m->nr);
+  sb_permute(m, x, xp);
+  if (m->nc > m->nr)
+    sb_d2d(xp + m->nr, x + m->nr, (size_t)(m->nc - m->nr) * sizeof(double));
+  launch_spmv(m, xp, yp, nullptr, nullptr);
+  sb_unpermute(m, yp, y);
+}
+
+static void launch_waxpby(uint32_t n, double alpha, const double* x, double beta, const double* y,
+    double* w, const int* stop)
+{
+  if (n == 0) return;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w) & 15u) SB_FATAL("waxpby: vectors must be 16-byte aligned");
+  hipLaunchKernelGGL(waxpby_k, dim3(stream_grid(n / 2 + 1, 256)), dim3(256), 0, g.stream, n, alpha, x,
+      beta, y, w, stop);
+  HIP_CHECK(hipGetLastError());
+}
+
+void sb_waxpby(uint32_t n, double alpha, const double* x, double beta, const double* y, double* w)
+{
+  need_init();
+  launch_waxpby(n, alpha, x, beta, y, w, nullptr);
+}
+
+// OP 0 dot(a,b) / OP 1 x,r update + r.r / OP 2 r = b - Ap + r.r  (kernels.hip.h: dot_spans_k);
+// partials receives 4*ceil(n/256) level-0 partials (tail zeroed)
+static void launch_dot_spans(int op, uint32_t n, const double* a, const double* b, double* x, double* r,
+    const CgScalars* S, double* partials, const int* stop)
+{
+  if (n == 0) return;
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)x | (uintptr_t)r) & 15u) SB_FATAL("vectors must be 16-byte aligned");
+  const uint32_t nSpans = ((n + 255u) / 256u) * 2u;
+  const dim3 grid(stream_grid(nSpans, 4)), block(256);
+  if (op == 0) hipLaunchKernelGGL((dot_spans_k<0>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
+  else if (op == 1) hipLaunchKernelGGL((dot_spans_k<1>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
+  else if (op == 2) hipLaunchKernelGGL((dot_spans_k<2>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
+  else hipLaunchKernelGGL((dot_spans_k<3>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
+  HIP_CHECK(hipGetLastError());
+}
+
+void sb_ddot_partials(uint32_t n, const double* x, const double* y, double* partials_dev)
+{
+  need_init();
+  launch_dot_spans(0, n, x, y, nullptr, nullptr, nullptr, partials_dev, nullptr);
+}
+
+void sb_reduce_final(uint32_t m, const double* partials_dev, double* result_dev)
+{
+  need_init();
+  hipLaunchKernelGGL(reduce_final_k, dim3(1), dim3(1024), 0, g.stream, m, partials_dev, result_dev,
+      (const int*)nullptr);
+  HIP_CHECK(hipGetLastError());
+}
+
+void sb_ddot_async(uint32_t n, const double* x, const double* y, double* result_dev)
+{
+  need_init();
+  const uint32_t m = (n + 255u) / 256u;
+  double* q        = scratch_partials(4 * (size_t)m);
+  sb_ddot_partials(n, x, y, q);
+  sb_reduce_final(m, q, result_dev);
+  if (multi_rank()) sb_comm_reduction(result_dev, 1);
+}
+
+double sb_ddot(uint32_t n, const double* x, const double* y)
+{
+  need_init();
+  sb_ddot_async(n, x, y, g.scalar);
+  double r = 0.0;
+  sb_d2h(&r, g.scalar, sizeof r);
+  return r;
+}

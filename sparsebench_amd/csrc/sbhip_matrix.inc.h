@@ -1,0 +1,634 @@
+// sbhip_matrix.inc.h -- part of the single translation unit sbhip.hip (textual include, shares its
+// static context): matrices: upload, the compressed mirror (levels 1-5), CRS mirror, accessors.
+// ===========================================================================
+// matrices
+// ===========================================================================
+static void* upload(const void* host, size_t bytes)
+{
+  void* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, bytes ? bytes : 8));
+  if (bytes) HIP_CHECK(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+  return d;
+}
+
+static void build_crs_mirror(sb_matrix* m, const uint32_t* rowPtr, const uint32_t* colInd, const double* val);
+
+sb_matrix* sb_crs_upload(uint32_t nr, uint32_t nc, const uint32_t* rowPtr, const uint32_t* colInd,
+    const double* val)
+{
+  need_init();
+  sb_matrix* m = new sb_matrix();
+  m->fmt = 0, m->nr = nr, m->nc = nc, m->nnz = rowPtr[nr];
+  for (uint32_t i = 0; i < nr; i++)
+    if (rowPtr[i + 1] < rowPtr[i]) SB_FATAL("CRS rowPtr not monotone at row %u", i);
+  for (uint32_t k = 0; k < m->nnz; k++)
+    if (colInd[k] >= nc) SB_FATAL("CRS colInd[%u]=%u out of range (nc=%u)", k, colInd[k], nc);
+  // Row blocks: as many rows as fit CRS_TILE nonzeros and CRS_THREADS rows; a row
+  // longer than the tile gets a block of its own.
+  std::vector<uint32_t> rb;
+  rb.push_back(0);
+  uint32_t r = 0;
+  while (r < nr) {
+    uint32_t start = r, base = rowPtr[r];
+    while (r < nr && r - start < (uint32_t)CRS_THREADS && rowPtr[r + 1] - base <= (uint32_t)CRS_TILE) r++;
+    if (r == start) r++; // single oversize row
+    rb.push_back(r);
+  }
+  m->nRowBlocks = (uint32_t)rb.size() - 1;
+  m->rowBlocks  = (uint32_t*)upload(rb.data(), rb.size() * sizeof(uint32_t));
+  m->rowPtr     = (uint32_t*)upload(rowPtr, ((size_t)nr + 1) * sizeof(uint32_t));
+  m->colInd     = (uint32_t*)upload(colInd, (size_t)m->nnz * sizeof(uint32_t));
+  m->val        = (double*)upload(val, (size_t)m->nnz * sizeof(double));
+  build_crs_mirror(m, rowPtr, colInd, val);
+  return m;
+}
+
+__global__ void remap_cols_k(uint32_t n, uint32_t nr, const uint32_t* __restrict__ oldToNew,
+    uint32_t* colInd)
+{
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t c = colInd[i];
+    if (c < nr) colInd[i] = oldToNew[c];
+  }
+}
+
+// Build the compressed mirror of an uploaded SCS C=64 matrix (pack.hip.h).  hostVal is
+// the host copy of val (dictionary detection happens on the host, with early exit).
+static void build_packed(sb_matrix* m, const double* hostVal, const uint32_t* oldToNewPerm)
+{
+  if (m->fmt != 1 || m->C != 64 || m->nChunks == 0) return;
+  const char* env = getenv("SB_PACK");
+  const int want  = env ? atoi(env) : 2; // 0 off, 1 columns only, 2 columns + values
+  if (want <= 0) return;
+  // 1. value dictionary (<= 256 distinct bit patterns, +0.0 always present for padding)
+  std::vector<unsigned long long> dict;
+  dict.push_back(0ull);
+  bool dictOk = want >= 2;
+  if (dictOk) {
+    unsigned long long last = 0ull;
+    for (size_t i = 0; i < m->nElems; i++) {
+      unsigned long long b;
+      memcpy(&b, hostVal + i, 8);
+      if (b == last) continue;
+      last = b;
+      if (std::find(dict.begin(), dict.end(), b) == dict.end()) {
+        dict.push_back(b);
+        if (dict.size() > 256) {
+          dictOk = false;
+          break;
+        }
+      }
+    }
+  }
+  std::sort(dict.begin(), dict.end());
+  m->nDict  = dictOk ? (int)dict.size() : 0;
+  m->padCol = (m->permuted && oldToNewPerm && m->nr) ? oldToNewPerm[0] : 0u;
+  // 2. per-chunk column range on the device
+  uint32_t *cmin = nullptr, *cmax = nullptr;
+  HIP_CHECK(hipMalloc(&cmin, (size_t)m->nChunks * sizeof(uint32_t)));
+  HIP_CHECK(hipMalloc(&cmax, (size_t)m->nChunks * sizeof(uint32_t)));
+  const dim3 grid((m->nChunks + 3) / 4), block(256);
+  hipLaunchKernelGGL(pack_minmax_k, grid, block, 0, g.stream, m->chunkPtr, m->chunkLens, m->colInd, m->val,
+      m->nChunks, m->padCol, cmin, cmax);
+  HIP_CHECK(hipGetLastError());
+  std::vector<uint32_t> lo(m->nChunks), hi(m->nChunks), lens(m->nChunks);
+  sb_d2h(lo.data(), cmin, lo.size() * sizeof(uint32_t));
+  sb_d2h(hi.data(), cmax, hi.size() * sizeof(uint32_t));
+  sb_d2h(lens.data(), m->chunkLens, lens.size() * sizeof(uint32_t));
+  HIP_CHECK(hipFree(cmin));
+  HIP_CHECK(hipFree(cmax));
+  // 3. stream positions
+  std::vector<PackMeta> meta(m->nChunks);
+  uint64_t grp = 0, units = 0;
+  m->nWideChunks = 0;
+  for (uint32_t c = 0; c < m->nChunks; c++) {
+    const bool empty = lo[c] > hi[c];
+    const bool wide  = !empty && (hi[c] - lo[c]) >= 0xFFFFu;
+    const uint32_t ng = (lens[c] + 3u) / 4u;
+    meta[c].grp    = (uint32_t)grp;
+    meta[c].idxOff = (uint32_t)units;
+    meta[c].base   = empty ? 0u : lo[c];
+    meta[c].info   = lens[c] | (wide ? 0x80000000u : 0u);
+    grp += ng;
+    units += (uint64_t)ng * (wide ? 2u : 1u);
+    m->nWideChunks += wide;
+  }
+  if (grp > 0xFFFFFFFFull || units > 0xFFFFFFFFull) return; // does not fit the 32-bit positions
+  m->pmeta = (PackMeta*)upload(meta.data(), meta.size() * sizeof(PackMeta));
+  HIP_CHECK(hipMalloc(&m->pidx, (size_t)units * 512 + 1024));
+  unsigned long long* dbits = nullptr;
+  if (m->nDict) {
+    HIP_CHECK(hipMalloc(&m->pcodes, (size_t)grp * 256 + 1024));
+    std::vector<unsigned long long> padded(256, 0ull);
+    std::copy(dict.begin(), dict.end(), padded.begin());
+    dbits    = (unsigned long long*)upload(dict.data(), dict.size() * sizeof(unsigned long long));
+    m->pdict = (double*)upload(padded.data(), 256 * sizeof(double));
+  }
+  hipLaunchKernelGGL(pack_write_k, grid, block, 0, g.stream, m->chunkPtr, m->chunkLens, m->colInd, m->val,
+      m->pmeta, dbits, m->nDict, m->nChunks, m->padCol, m->pidx, m->pcodes);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  if (dbits) HIP_CHECK(hipFree(dbits));
+  m->packLevel   = m->nDict ? 2 : 1;
+  m->usePacked   = 1;
+  m->packedBytes = (double)units * 512.0 + (m->nDict ? (double)grp * 256.0 : 8.0 * m->nElems) +
+                   16.0 * m->nChunks;
+}
+
+// Level 3 of the compressed mirror: per tile (4 chunks = one workgroup) the contiguous
+// column ranges its rows touch, so the kernel can stage them in LDS (pack.hip.h).
+// Host arrays are the reference-layout ones (columns in ORIGINAL numbering).
+static void build_lds_windows(sb_matrix* m, const uint32_t* chunkPtr, const uint32_t* chunkLens,
+    const uint32_t* colInd, const double* val, const uint32_t* oldToNewPerm)
+{
+  if (m->packLevel < 1) return;
+  const char* env = getenv("SB_PACK");
+  if ((env ? atoi(env) : 3) < 3) return;
+  const uint32_t WMAX = 6144, MERGE_GAP = 8; // window <= 48 KiB of LDS per workgroup
+  const uint32_t nTiles = (m->nChunks + 3) / 4;
+  std::vector<uint32_t> segPtr(nTiles + 1, 0);
+  std::vector<TileSeg> segs;
+  std::vector<uint32_t> cols;
+  std::vector<uint64_t> bitmap;
+  uint32_t maxWin = 0;
+  uint64_t sumWin = 0, sumElems = 0;
+  for (uint32_t t = 0; t < nTiles; t++) {
+    cols.clear();
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+    for (uint32_t c = t * 4; c < std::min(t * 4 + 4, m->nChunks); c++) {
+      const size_t cp = chunkPtr[c];
+      const size_t n  = (size_t)chunkLens[c] * 64;
+      for (size_t e = 0; e < n; e++) {
+        uint32_t col = colInd[cp + e];
+        unsigned long long bits;
+        memcpy(&bits, val + cp + e, 8);
+        if (col == 0 && bits == 0) continue; // padding (or an explicit 0.0 at column 0): slot 0
+        if (m->permuted && col < m->nr) col = oldToNewPerm[col];
+        cols.push_back(col);
+        lo = std::min(lo, col), hi = std::max(hi, col);
+      }
+    }
+    segPtr[t] = (uint32_t)segs.size();
+    if (cols.empty()) continue;
+    // distinct columns in ascending order: bitmap when the span is modest, sort otherwise
+    const uint64_t span = (uint64_t)hi - lo + 1;
+    uint32_t win = 1; // slot 0
+    auto emit = [&](uint32_t first, uint32_t last) {
+      TileSeg s;
+      s.col = first, s.len = last - first + 1, s.lds = win, s.pad_ = 0;
+      win += s.len;
+      segs.push_back(s);
+    };
+    if (span <= (1u << 22)) {
+      bitmap.assign((span + 63) / 64, 0ull);
+      for (uint32_t c : cols) bitmap[(c - lo) >> 6] |= 1ull << ((c - lo) & 63);
+      bool open = false;
+      uint32_t first = 0, last = 0;
+      for (uint64_t w = 0; w < bitmap.size(); w++) {
+        uint64_t bits = bitmap[w];
+        while (bits) {
+          const uint32_t c = lo + (uint32_t)(w * 64 + (uint64_t)__builtin_ctzll(bits));
+          bits &= bits - 1;
+          if (!open) first = last = c, open = true;
+          else if (c - last <= MERGE_GAP) last = c;
+          else emit(first, last), first = last = c;
+        }
+      }
+      if (open) emit(first, last);
+    } else {
+      std::sort(cols.begin(), cols.end());
+      uint32_t first = cols[0], last = cols[0];
+      for (uint32_t c : cols) {
+        if (c - last <= MERGE_GAP) last = std::max(last, c);
+        else emit(first, last), first = last = c;
+      }
+      emit(first, last);
+    }
+    if (win > WMAX) return; // some tile's window does not fit LDS: stay at level 1/2
+    maxWin = std::max(maxWin, win);
+    sumWin += win;
+    sumElems += cols.size();
+  }
+  segPtr[nTiles] = (uint32_t)segs.size();
+  // Staging pays only when a window entry is reused several times and the window is made
+  // of long runs (coalesced copies).  Measured: 27-pt stencil reuse 4.6 / run ~510 ->
+  // 1.15x faster than gathering through the cache; irregular FE-like matrix with 5 % far
+  // couplings reuse 2.5 / run ~3 -> 2.5x slower.  SB_PACK_LDS=1 forces it on, =0 off.
+  {
+    const double reuse = sumWin ? (double)sumElems / (double)sumWin : 0.0;
+    const double run   = segs.empty() ? 0.0 : (double)sumWin / (double)segs.size();
+    const char* force  = getenv("SB_PACK_LDS");
+    const bool want    = force ? atoi(force) != 0 : (reuse >= 3.0 && run >= 32.0);
+    if (!want) return;
+  }
+  if (maxWin == 0) maxWin = 1;
+  TileSeg dummy = { 0, 0, 0, 0 };
+  if (segs.empty()) segs.push_back(dummy);
+  m->tileSegPtr = (uint32_t*)upload(segPtr.data(), segPtr.size() * sizeof(uint32_t));
+  m->tileSegs   = (TileSeg*)upload(segs.data(), segs.size() * sizeof(TileSeg));
+  std::vector<PackMeta> meta(m->nChunks);
+  sb_d2h(meta.data(), m->pmeta, meta.size() * sizeof(PackMeta));
+  const uint64_t groups = meta.empty() ? 0 : (uint64_t)meta.back().grp + ((meta.back().info & 0x7FFFFFFFu) + 3u) / 4u;
+  HIP_CHECK(hipMalloc(&m->pslots, (size_t)groups * 512 + 1024));
+  hipLaunchKernelGGL(pack_slots_k, dim3(nTiles), dim3(256), 0, g.stream, m->chunkPtr, m->chunkLens, m->colInd,
+      m->val, m->pmeta, m->tileSegPtr, m->tileSegs, m->nChunks, m->padCol, m->pslots);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  m->ldsWindow = maxWin;
+  m->slotBytes = (double)groups * 512.0 + (m->nDict ? (double)groups * 256.0 : 8.0 * m->nElems) +
+                 16.0 * m->nChunks + 16.0 * segs.size() + 4.0 * nTiles;
+  m->usePacked = 2; // 2: packed stream + x window in LDS
+}
+
+// Level 4: one byte per element naming a (value, slot delta) pair of the tile's class;
+// level 5: per chunk one shared row pattern + the odd lanes (pack.hip.h).  Needs the value
+// dictionary and the LDS windows.  SB_PACK=4 stops at level 4 (every chunk per-lane).
+static void build_patterns(sb_matrix* m)
+{
+  if (m->usePacked != 2 || m->nDict <= 0) return;
+  const char* env = getenv("SB_PACK");
+  if ((env ? atoi(env) : 4) < 4) return;
+  const uint32_t nTiles = (m->nChunks + 3) / 4;
+  uint32_t *dCount = nullptr, *dKeys = nullptr;
+  HIP_CHECK(hipMalloc(&m->rowBase, (size_t)m->nChunks * 64 * sizeof(uint16_t) + 16));
+  HIP_CHECK(hipMalloc(&dCount, (size_t)nTiles * sizeof(uint32_t)));
+  HIP_CHECK(hipMalloc(&dKeys, (size_t)nTiles * 256 * sizeof(uint32_t)));
+  hipLaunchKernelGGL(pat_collect_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, m->pslots, m->pcodes,
+      m->nChunks, m->rowBase, dCount, dKeys);
+  HIP_CHECK(hipGetLastError());
+  std::vector<uint32_t> count(nTiles), keys((size_t)nTiles * 256);
+  sb_d2h(count.data(), dCount, count.size() * sizeof(uint32_t));
+  sb_d2h(keys.data(), dKeys, keys.size() * sizeof(uint32_t));
+  HIP_CHECK(hipFree(dCount));
+  HIP_CHECK(hipFree(dKeys));
+  auto giveUp = [&]() { sb_free(m->rowBase), m->rowBase = nullptr; };
+  for (uint32_t t = 0; t < nTiles; t++)
+    if (count[t] > PAT_MAX) return giveUp();
+  // tiles -> classes of <= PAT_MAX pairs: a class that already holds the tile's pairs,
+  // else the first class the pairs still fit into, else a new class
+  std::vector<std::vector<uint32_t>> classes;
+  std::vector<uint32_t> tileClass(nTiles, 0), merged;
+  const size_t maxClasses = std::max<size_t>(64, nTiles / 4);
+  uint32_t lastClass = 0;
+  for (uint32_t t = 0; t < nTiles; t++) {
+    uint32_t* k = keys.data() + (size_t)t * 256;
+    std::sort(k, k + count[t]);
+    int found = -1;
+    if (!classes.empty() && std::includes(classes[lastClass].begin(), classes[lastClass].end(), k, k + count[t]))
+      found = (int)lastClass;
+    for (size_t c = 0; found < 0 && c < classes.size(); c++)
+      if (std::includes(classes[c].begin(), classes[c].end(), k, k + count[t])) found = (int)c;
+    for (size_t c = 0; found < 0 && c < classes.size(); c++) {
+      merged.clear();
+      std::set_union(classes[c].begin(), classes[c].end(), k, k + count[t], std::back_inserter(merged));
+      if (merged.size() <= PAT_MAX) classes[c] = merged, found = (int)c;
+    }
+    if (found < 0) {
+      if (classes.size() >= maxClasses) return giveUp(); // no repeating patterns: not worth the tables
+      classes.emplace_back(k, k + count[t]);
+      found = (int)classes.size() - 1;
+    }
+    tileClass[t] = lastClass = (uint32_t)found;
+  }
+  if (classes.empty()) classes.emplace_back();
+  std::vector<double> dict(256);
+  sb_d2h(dict.data(), m->pdict, 256 * sizeof(double));
+  std::vector<uint32_t> classKeys(classes.size() * 256, PAT_EMPTY);
+  std::vector<PatEntry> classDict(classes.size() * 256, PatEntry{ 0.0, 0, 0u });
+  for (size_t c = 0; c < classes.size(); c++)
+    for (size_t i = 0; i < classes[c].size(); i++) {
+      const uint32_t key       = classes[c][i];
+      classKeys[c * 256 + i]   = key;
+      PatEntry& e              = classDict[c * 256 + i];
+      e.v                      = dict[key & 255u];
+      if (key & PAT_ABS) e.off8 = 0u, e.m = 0u; // padding: slot 0
+      else e.off8 = (uint32_t)(8 * ((int32_t)((key >> 8) & 0xFFFFu) - 32768)), e.m = 1u; // 8 * (slot - rowBase), mod 2^32
+    }
+  uint32_t* dClassKeys = (uint32_t*)upload(classKeys.data(), classKeys.size() * sizeof(uint32_t));
+  m->tileClass         = (uint32_t*)upload(tileClass.data(), tileClass.size() * sizeof(uint32_t));
+  m->classDict         = (PatEntry*)upload(classDict.data(), classDict.size() * sizeof(PatEntry));
+  std::vector<PackMeta> meta(m->nChunks);
+  sb_d2h(meta.data(), m->pmeta, meta.size() * sizeof(PackMeta));
+  const uint64_t groups = (uint64_t)meta.back().grp + ((meta.back().info & 0x7FFFFFFFu) + 3u) / 4u;
+  for (const PackMeta& pm : meta)
+    if ((pm.info & 0x7FFFFFFFu) >= PAT_NOPAD) { // chunk width collides with the header's flag bits
+      sb_free(dClassKeys), sb_free(m->tileClass), sb_free(m->classDict);
+      m->tileClass = nullptr, m->classDict = nullptr;
+      return giveUp();
+    }
+  uint32_t* lanes = nullptr; // per-lane code words, group-major (the L form of every chunk)
+  HIP_CHECK(hipMalloc(&lanes, (size_t)groups * 256 + 1024));
+  hipLaunchKernelGGL(pat_encode_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, m->pslots, m->pcodes,
+      m->nChunks, m->rowBase, m->tileClass, dClassKeys, lanes);
+  HIP_CHECK(hipGetLastError());
+  // Level 5 (row patterns): dominant code sequence and exception lanes of every chunk
+  const bool wantRows = (env ? atoi(env) : 5) >= 5;
+  uint32_t *dDom = nullptr, *dExc = nullptr;
+  HIP_CHECK(hipMalloc(&dDom, (size_t)groups * sizeof(uint32_t) + 16));
+  HIP_CHECK(hipMalloc(&dExc, (size_t)m->nChunks * 2 * sizeof(uint32_t)));
+  hipLaunchKernelGGL(pat_dominant_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dDom,
+      dExc);
+  HIP_CHECK(hipGetLastError());
+  std::vector<uint32_t> dom(groups ? groups : 1), exc((size_t)m->nChunks * 2);
+  sb_d2h(dom.data(), dDom, (size_t)groups * sizeof(uint32_t));
+  sb_d2h(exc.data(), dExc, exc.size() * sizeof(uint32_t));
+  HIP_CHECK(hipFree(dDom));
+  // chunk by chunk: U (row pattern + expanded exception lanes) or L (code words of all 64
+  // lanes); row patterns are shared between chunks (key: the expanded entries).  A tile's
+  // exception entries are staged in LDS, so a tile with too many of them stays L.
+  const size_t maxPatEntries = 1u << 20; // 16 MiB of pattern rows at most
+  std::vector<PatEntry> rowPats;
+  std::unordered_map<std::string, uint32_t> patIndex;
+  std::vector<uint32_t> chunkOff(m->nChunks), chunkFlags(m->nChunks), chunkPat(m->nChunks, 0);
+  std::vector<uint32_t> tileExcStart(nTiles, 0), tileExcCount(nTiles, 0);
+  std::vector<PatEntry> row;
+  uint64_t words = 0, excEntries = 0;
+  uint32_t excLds = 0;
+  bool anyL       = false;
+  m->nUniformChunks = 0;
+  auto n_exc = [&](uint32_t c) {
+    return (uint32_t)__builtin_popcount(exc[2 * (size_t)c]) + (uint32_t)__builtin_popcount(exc[2 * (size_t)c + 1]);
+  };
+  for (uint32_t t = 0; t < nTiles; t++) {
+    const uint32_t c0 = t * 4, c1 = std::min(c0 + 4, m->nChunks);
+    uint64_t tileExc = 0;
+    bool tileOk      = wantRows;
+    for (uint32_t c = c0; c < c1 && tileOk; c++) {
+      const uint32_t len = meta[c].info & 0x7FFFFFFFu;
+      if (len == 0 || n_exc(c) > PAT_EXC_MAX) continue; // this chunk will be L
+      tileExc += (uint64_t)n_exc(c) * len;
+    }
+    if (tileExc > PAT_EXC_LDS_MAX) tileOk = false;
+    tileExcStart[t] = (uint32_t)excEntries;
+    for (uint32_t c = c0; c < c1; c++) {
+      const uint32_t len = meta[c].info & 0x7FFFFFFFu, ng = (len + 3u) / 4u, nExc = n_exc(c);
+      bool uni = tileOk && len > 0 && nExc <= PAT_EXC_MAX, nopad = true;
+      if (uni) {
+        row.resize(len);
+        const PatEntry* cd = classDict.data() + (size_t)tileClass[t] * 256;
+        for (uint32_t j = 0; j < len; j++) {
+          row[j] = cd[(dom[meta[c].grp + j / 4] >> (8u * (j & 3u))) & 255u];
+          nopad  = nopad && row[j].m == 1u;
+        }
+        std::string key((const char*)row.data(), row.size() * sizeof(PatEntry));
+        auto it = patIndex.find(key);
+        if (it != patIndex.end()) chunkPat[c] = it->second;
+        else if (rowPats.size() + len <= maxPatEntries) {
+          chunkPat[c] = (uint32_t)rowPats.size();
+          patIndex.emplace(std::move(key), chunkPat[c]);
+          rowPats.insert(rowPats.end(), row.begin(), row.end());
+        } else uni = false; // table full
+      }
+      if (uni) {
+        chunkOff[c]   = (uint32_t)excEntries;
+        chunkFlags[c] = len | PAT_UNIFORM | (nopad ? PAT_NOPAD : 0u);
+        excEntries += (uint64_t)nExc * len;
+        tileExcCount[t] += nExc * len;
+        m->nUniformChunks++;
+      } else {
+        chunkOff[c]   = (uint32_t)words;
+        chunkFlags[c] = len;
+        words += (uint64_t)ng * 64u;
+        anyL = anyL || len > 0;
+      }
+    }
+    excLds = std::max(excLds, tileExcCount[t]);
+  }
+  if (words > 0xFFFFFFFFull || excEntries > 0xFFFFFFFFull) {
+    sb_free(lanes), sb_free(dExc), sb_free(dClassKeys);
+    sb_free(m->classDict), m->classDict = nullptr;
+    return giveUp();
+  }
+  uint32_t* dOff   = (uint32_t*)upload(chunkOff.data(), chunkOff.size() * sizeof(uint32_t));
+  uint32_t* dFlags = (uint32_t*)upload(chunkFlags.data(), chunkFlags.size() * sizeof(uint32_t));
+  const size_t streamBytes = (size_t)words * sizeof(uint32_t) + 1024;          // slack: clamped reads
+  const size_t excBytes    = ((size_t)excEntries + 520) * sizeof(PatEntry);     // slack: 2 x 256 unconditional reads
+  HIP_CHECK(hipMalloc(&m->jcodes, streamBytes));
+  HIP_CHECK(hipMalloc(&m->excRows, excBytes));
+  HIP_CHECK(hipMemsetAsync(m->jcodes, 0, streamBytes, g.stream));
+  HIP_CHECK(hipMemsetAsync(m->excRows, 0, excBytes, g.stream));
+  hipLaunchKernelGGL(pat_compact_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dOff,
+      dFlags, dExc, m->rowBase, m->tileClass, m->classDict, m->jcodes, m->excRows);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  sb_free(lanes), sb_free(dExc), sb_free(dOff), sb_free(dFlags), sb_free(dClassKeys);
+  if (rowPats.empty()) rowPats.push_back(PatEntry{ 0.0, 0u, 0u });
+  m->rowPats     = (PatEntry*)upload(rowPats.data(), rowPats.size() * sizeof(PatEntry));
+  m->nRowPats    = (uint32_t)patIndex.size();
+  m->nPatClasses = (uint32_t)classes.size();
+  m->patDict     = anyL ? 256u : 0u;
+  m->patExcLds   = excLds;
+  // one header per tile: class, chunk positions / widths / row patterns, the first segments
+  std::vector<uint32_t> segPtr(nTiles + 1);
+  sb_d2h(segPtr.data(), m->tileSegPtr, segPtr.size() * sizeof(uint32_t));
+  const size_t nSegs = segPtr[nTiles];
+  std::vector<TileSeg> segs(std::max<size_t>(nSegs, 1));
+  if (nSegs) sb_d2h(segs.data(), m->tileSegs, nSegs * sizeof(TileSeg));
+  std::vector<TileHdr> hdrs(nTiles);
+  for (uint32_t t = 0; t < nTiles; t++) {
+    TileHdr& h = hdrs[t];
+    memset(&h, 0, sizeof h);
+    h.tile = t;
+    h.cls = tileClass[t], h.nseg = segPtr[t + 1] - segPtr[t], h.segPtr = segPtr[t], h.win = 1;
+    h.excStart = tileExcStart[t], h.excCount = tileExcCount[t];
+    for (uint32_t w = 0; w < 4; w++) {
+      const uint32_t c = t * 4 + w;
+      if (c >= m->nChunks) continue;
+      h.off[w] = chunkOff[c], h.len[w] = chunkFlags[c], h.rowPat[w] = chunkPat[c];
+      if (chunkFlags[c] & PAT_UNIFORM) h.exc[w][0] = exc[2 * (size_t)c], h.exc[w][1] = exc[2 * (size_t)c + 1];
+    }
+    for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++) h.seg[s][1] = 0xFFFFFFFFu;
+    h.winInline = 1;
+    // simple window: <= 6 segments which, longest first, are 3 x <= 768 and 3 x <= 256 entries
+    std::vector<TileSeg> ts(segs.begin() + segPtr[t], segs.begin() + segPtr[t] + h.nseg);
+    std::stable_sort(ts.begin(), ts.end(), [](const TileSeg& a, const TileSeg& b) { return a.len > b.len; });
+    bool simple = h.nseg <= PAT_INLINE_SEGS;
+    for (uint32_t s = 0; s < h.nseg && simple; s++) simple = ts[s].len <= (s < 3 ? 768u : 256u);
+    for (uint32_t s = 0; s < h.nseg; s++) {
+      const TileSeg& sg = simple ? ts[s] : segs[segPtr[t] + s]; // slot order unless simple
+      if (s < PAT_INLINE_SEGS) h.seg[s][0] = sg.col, h.seg[s][1] = sg.lds, h.seg[s][2] = sg.len;
+    }
+    for (uint32_t s = 0; s < h.nseg; s++) {
+      const TileSeg& sg = segs[segPtr[t] + s];
+      if (s < PAT_INLINE_SEGS) h.winInline = sg.lds + sg.len;
+      h.win = sg.lds + sg.len;
+    }
+    h.flags = simple ? PAT_SIMPLE_WINDOW : 0u;
+  }
+  // tiles whose window holds a halo column (>= nr) go last: the interior part of the product
+  // does not have to wait for the halo exchange (loop_body)
+  m->patInterior = nTiles;
+  if (m->nc > m->nr) {
+    auto touches_halo = [&](const TileHdr& h) {
+      for (uint32_t s2 = 0; s2 < h.nseg; s2++) {
+        const TileSeg& sg = segs[h.segPtr + s2];
+        if (sg.col + sg.len > m->nr) return true;
+      }
+      return false;
+    };
+    auto mid = std::stable_partition(hdrs.begin(), hdrs.end(), [&](const TileHdr& h) { return !touches_halo(h); });
+    m->patInterior = (uint32_t)(mid - hdrs.begin());
+  }
+  m->tileHdrs = (TileHdr*)upload(hdrs.data(), hdrs.size() * sizeof(TileHdr));
+  if (getenv("SB_PACK_REPORT")) {
+    size_t nSimple = 0;
+    for (const TileHdr& h : hdrs) nSimple += h.flags & PAT_SIMPLE_WINDOW;
+    fprintf(stderr, "sbhip pack: %u tiles (%u interior, %zu simple windows, max %u entries), %u classes, %u/%u U chunks, "
+                    "%zu row patterns (%zu entries), %llu exception entries (max %u per tile), %llu code words\n",
+        nTiles, m->patInterior, nSimple, m->ldsWindow, m->nPatClasses, m->nUniformChunks, m->nChunks, patIndex.size(),
+        rowPats.size(), (unsigned long long)excEntries, excLds, (unsigned long long)words);
+  }
+  m->patBytes = (double)words * 4.0 + 16.0 * (double)excEntries + 2.0 * 64.0 * m->nChunks + 16.0 * nSegs +
+                (double)sizeof(TileHdr) * nTiles + (anyL ? 4096.0 * classes.size() : 0.0) + 16.0 * rowPats.size();
+  // Default kernel: the pattern kernel once the matrix is more than one round of resident
+  // workgroups (8 per CU); below that everything is one dependent-latency chain and the
+  // level-3 kernel's is shorter (64^3: 46.7k vs 43.2k CG it/s; 96^3: 22.8k vs 26.3k).
+  // sb_matrix_use_packed(m, 3) selects it regardless.
+  m->usePacked = nTiles > (uint32_t)g.prop.multiProcessorCount * 8u ? 3 : 2;
+}
+
+sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, uint32_t nChunks,
+    uint32_t nElems, const uint32_t* chunkPtr, const uint32_t* chunkLens, const uint32_t* colInd,
+    const double* val, const uint32_t* oldToNewPerm, const uint32_t* newToOldPerm)
+{
+  need_init();
+  if (C == 0) SB_FATAL("SCS chunk height C must be >= 1");
+  if ((uint64_t)nChunks * C < nr) SB_FATAL("SCS nChunks*C < nr");
+  if (chunkPtr[nChunks] != nElems) SB_FATAL("SCS chunkPtr[nChunks] != nElems");
+  for (uint32_t c = 0; c < nChunks; c++)
+    if (chunkPtr[c + 1] - chunkPtr[c] != chunkLens[c] * C)
+      SB_FATAL("SCS chunk %u: chunkPtr/chunkLens inconsistent", c);
+  for (uint32_t k = 0; k < nElems; k++)
+    if (colInd[k] >= nc) SB_FATAL("SCS colInd[%u]=%u out of range (nc=%u)", k, colInd[k], nc);
+  sb_matrix* m = new sb_matrix();
+  m->fmt = 1, m->nr = nr, m->nc = nc, m->C = C, m->sigma = sigma, m->nChunks = nChunks;
+  m->nElems = nElems, m->nrPadded = nChunks * C, m->nnz = nElems;
+  int permuted = 0;
+  if (oldToNewPerm)
+    for (uint32_t i = 0; i < nr; i++) {
+      if (oldToNewPerm[i] >= nr) SB_FATAL("SCS oldToNewPerm[%u]=%u out of range", i, oldToNewPerm[i]);
+      if (oldToNewPerm[i] != i) permuted = 1;
+    }
+  if (permuted && !newToOldPerm) SB_FATAL("SCS permuted matrix needs newToOldPerm");
+  m->permuted  = permuted;
+  m->chunkPtr  = (uint32_t*)upload(chunkPtr, ((size_t)nChunks + 1) * sizeof(uint32_t));
+  m->chunkLens = (uint32_t*)upload(chunkLens, (size_t)nChunks * sizeof(uint32_t));
+  // SCS_SLACK zeroed elements behind the data: the pipelined kernel prefetches up to
+  // U-1 columns past a chunk's end
+  HIP_CHECK(hipMalloc(&m->colInd, ((size_t)nElems + SCS_SLACK) * sizeof(uint32_t)));
+  HIP_CHECK(hipMalloc(&m->val, ((size_t)nElems + SCS_SLACK) * sizeof(double)));
+  HIP_CHECK(hipMemset(m->colInd + nElems, 0, SCS_SLACK * sizeof(uint32_t)));
+  HIP_CHECK(hipMemset(m->val + nElems, 0, SCS_SLACK * sizeof(double)));
+  if (nElems) {
+    HIP_CHECK(hipMemcpy(m->colInd, colInd, (size_t)nElems * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(m->val, val, (size_t)nElems * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (permuted) {
+    m->oldToNew = (uint32_t*)upload(oldToNewPerm, (size_t)nr * sizeof(uint32_t));
+    m->newToOld = (uint32_t*)upload(newToOldPerm, (size_t)nr * sizeof(uint32_t));
+    hipLaunchKernelGGL(remap_cols_k, dim3(stream_grid(nElems, 256)), dim3(256), 0, g.stream, nElems,
+        nr, m->oldToNew, m->colInd);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+  }
+  build_packed(m, val, oldToNewPerm);
+  build_lds_windows(m, chunkPtr, chunkLens, colInd, val, oldToNewPerm);
+  build_patterns(m);
+  return m;
+}
+
+// CRS: a device-private Sell-64-1 mirror that exists only for its pattern levels (pack.hip.h).
+// Row sums are taken left to right exactly as src/matrix-CRS.c:46-65 does; the SKIPPAD kernel
+// does not add the mirror's padding, so the result is the CRS loop's bit for bit.  Kept only
+// when the pattern levels could be built; the native CRS kernel stays selectable
+// (sb_matrix_use_packed(m, 0)) and is the default for small matrices.
+static void build_crs_mirror(sb_matrix* m, const uint32_t* rowPtr, const uint32_t* colInd, const double* val)
+{
+  const char* env = getenv("SB_PACK");
+  if ((env ? atoi(env) : 5) < 4 || m->nr == 0 || m->nnz == 0) return;
+  const uint32_t nr = m->nr, nChunks = (nr + 63) / 64;
+  std::vector<uint32_t> chunkLens(nChunks, 0), chunkPtr(nChunks + 1, 0);
+  for (uint32_t i = 0; i < nr; i++) chunkLens[i / 64] = std::max(chunkLens[i / 64], rowPtr[i + 1] - rowPtr[i]);
+  uint64_t total = 0;
+  for (uint32_t c = 0; c < nChunks; c++) {
+    chunkPtr[c] = (uint32_t)total;
+    total += (uint64_t)chunkLens[c] * 64;
+  }
+  if (total > 0xFFFFFFFFull) return;
+  chunkPtr[nChunks] = (uint32_t)total;
+  std::vector<uint32_t> scol(total, 0u);
+  std::vector<double> sval(total, 0.0);
+  for (uint32_t i = 0; i < nr; i++) {
+    const size_t at = (size_t)chunkPtr[i / 64] + (i % 64);
+    for (uint32_t j = rowPtr[i]; j < rowPtr[i + 1]; j++) {
+      unsigned long long bits;
+      memcpy(&bits, val + j, 8);
+      // padding is (column 0, +0.0): a stored +0.0 at column 0 would be indistinguishable from it
+      if (colInd[j] == 0 && bits == 0) return;
+      scol[at + (size_t)(j - rowPtr[i]) * 64] = colInd[j];
+      sval[at + (size_t)(j - rowPtr[i]) * 64] = val[j];
+    }
+  }
+  sb_matrix* mm = sb_scs_upload(nr, m->nc, 64, 1, nChunks, (uint32_t)total, chunkPtr.data(), chunkLens.data(),
+      scol.data(), sval.data(), nullptr, nullptr);
+  if (mm->nPatClasses == 0) { // no repeating patterns: the native kernel it is
+    sb_matrix_free(mm);
+    return;
+  }
+  // only the pattern levels are used (the other SCS kernels add the padding)
+  sb_free(mm->val), sb_free(mm->colInd), sb_free(mm->pidx), sb_free(mm->pcodes), sb_free(mm->pslots);
+  mm->val = nullptr, mm->colInd = nullptr, mm->pidx = nullptr, mm->pcodes = nullptr, mm->pslots = nullptr;
+  m->mirror    = mm;
+  m->usePacked = mm->usePacked == 3 ? 3 : 0; // the same size rule as for SCS matrices
+}
+
+void sb_matrix_free(sb_matrix* m)
+{
+  if (!m) return;
+  sb_free(m->rowPtr), sb_free(m->rowBlocks), sb_free(m->chunkPtr), sb_free(m->chunkLens);
+  sb_free(m->oldToNew), sb_free(m->newToOld), sb_free(m->colInd), sb_free(m->val);
+  sb_free(m->pmeta), sb_free(m->pidx), sb_free(m->pcodes), sb_free(m->pdict);
+  sb_free(m->tileSegPtr), sb_free(m->tileSegs), sb_free(m->pslots);
+  sb_free(m->rowBase), sb_free(m->tileClass), sb_free(m->jcodes), sb_free(m->classDict), sb_free(m->tileHdrs), sb_free(m->rowPats), sb_free(m->excRows);
+  if (m->mirror) sb_matrix_free(m->mirror);
+  delete m;
+}
+
+int sb_matrix_pack_level(const sb_matrix* m) { return m->packLevel; }
+void sb_matrix_use_packed(sb_matrix* m, int mode)
+{ // 0 reference-layout stream, 1 packed stream + gathers through the cache, 2 packed + LDS window,
+  // 3 pattern codes + LDS window; a mode the matrix does not have falls to the next lower one
+  if (m->fmt == 0) m->usePacked = mode >= 3 && m->mirror ? 3 : 0;
+  else if (mode >= 3 && m->nPatClasses) m->usePacked = 3;
+  else if (mode >= 2 && m->ldsWindow) m->usePacked = 2;
+  else if (mode >= 1 && m->packLevel) m->usePacked = 1;
+  else m->usePacked = 0;
+}
+int sb_matrix_packed_mode(const sb_matrix* m) { return m->usePacked; }
+// the matrix whose pattern levels serve m: m itself (SCS) or its private mirror (CRS)
+static const sb_matrix* pat_of(const sb_matrix* m) { return m->fmt == 0 && m->mirror ? m->mirror : m; }
+uint32_t sb_matrix_lds_window(const sb_matrix* m) { return pat_of(m)->ldsWindow; }
+uint32_t sb_matrix_pattern_classes(const sb_matrix* m) { return pat_of(m)->nPatClasses; }
+uint32_t sb_matrix_row_patterns(const sb_matrix* m, uint32_t* uniformChunks)
+{
+  if (uniformChunks) *uniformChunks = pat_of(m)->nUniformChunks;
+  return pat_of(m)->nRowPats;
+}
+double sb_matrix_stream_bytes(const sb_matrix* m)
+{ // bytes the SELECTED SpMV kernel moves per launch (matrix stream + x once + y once)
+  if (m->fmt == 0 && m->usePacked == 3) return m->mirror->patBytes + 8.0 * m->mirror->nrPadded + 8.0 * m->nc;
+  if (m->fmt == 1 && m->usePacked == 3) return m->patBytes + 8.0 * m->nrPadded + 8.0 * m->nc;
+  if (m->fmt == 1 && m->usePacked == 2) return m->slotBytes + 8.0 * m->nrPadded + 8.0 * m->nc;
+  if (m->fmt == 1 && m->usePacked) return m->packedBytes + 8.0 * m->nrPadded + 8.0 * m->nc;
+  return sb_matrix_spmv_bytes(m);
+}
+uint32_t sb_matrix_nr(const sb_matrix* m) { return m->nr; }
+uint32_t sb_matrix_nc(const sb_matrix* m) { return m->nc; }
+int sb_matrix_is_permuted(const sb_matrix* m) { return m->permuted; }
+double sb_matrix_spmv_bytes(const sb_matrix* m)
+{
+  if (m->fmt == 0)
+    return 12.0 * m->nnz + 4.0 * ((double)m->nr + 1) + 8.0 * m->nr + 8.0 * m->nc;
+  return 12.0 * m->nElems + 8.0 * m->nChunks + 8.0 * m->nrPadded + 8.0 * m->nc;
+}

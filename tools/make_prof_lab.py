@@ -38,7 +38,7 @@ patch(W + "/sparsebench_amd/csrc/pack.hip.h", [
      "#ifdef LAB_EXIT_AFTER_BARRIER\n  if (row < nr) y[row] = xrow + (double)base + sx[lane] + se[lane].v;\n  return;\n#endif\n"),
     ("  if (row < nr) y[row] = acc;\n  if (DOT) {\n    double t2", "  PROF(4);\n  if (row < nr) y[row] = acc;\n  if (DOT) {\n    double t2"),
 ])
-patch(W + "/sparsebench_amd/csrc/sbhip.hip", [
+patch(W + "/sparsebench_amd/csrc/sbhip_matrix.inc.h", [
     ("uint32_t sb_matrix_pattern_classes(const sb_matrix* m) { return pat_of(m)->nPatClasses; }\n",
      "uint32_t sb_matrix_pattern_classes(const sb_matrix* m) { return pat_of(m)->nPatClasses; }\n"
      "extern \"C\" void sb_lab_prof(long long* out)\n{\n  HIP_CHECK(hipStreamSynchronize(g.stream));\n"

@@ -1,6 +1,6 @@
 """pattern_lab.py -- CPU feasibility study for the joint (value, slot-delta) dictionary.
 
-For a Sell-64-sigma matrix: emulate the tile windows of build_lds_windows (sbhip.hip),
+For a Sell-64-sigma matrix: emulate the tile windows of build_lds_windows (sbhip_matrix.inc.h),
 compute every element's LDS slot, and count the distinct pairs
     (value bits, slot - slot of the row's first stored element)
 over the whole matrix.  Few pairs (<= 255) mean one byte per element can replace
@@ -65,7 +65,7 @@ def study(n, sigma, Cc=64):
     top = set(k for k, _ in pairs.most_common(255))
     covered = sum(1 for ts in tile_sets if ts <= top)
     classes = []
-    for ts in tile_sets:  # the greedy clustering of build_patterns (sbhip.hip)
+    for ts in tile_sets:  # the greedy clustering of build_patterns (sbhip_matrix.inc.h)
         for i, c in enumerate(classes):
             if ts <= c:
                 break
