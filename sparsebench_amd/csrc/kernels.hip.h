@@ -586,7 +586,7 @@ __global__ __launch_bounds__(64) void p2p_selftest_k(const P2PView* pv, unsigned
 // CG scalar step as its own launch: the reference-shaped (unfused) path, and after the
 // all-reduce on several ranks (REDUCE = false: the sum is already in S->local).  With pv != NULL
 // the all-reduce happens right here (p2p_allreduce_sum) and the step follows in the same launch.
-template <int MODE, bool REDUCE>
+template <int MODE, bool REDUCE, bool P2P = false>
 __global__ __launch_bounds__(1024) void cg_scalar_k(uint32_t m, const double* __restrict__ q,
     CgScalars* S, double* __restrict__ rr_hist, double* __restrict__ pAp_hist, int to_local, int defer_x,
     const P2PView* pv, unsigned long long seq)
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(1024) void cg_scalar_k(uint32_t m, const double* __
       if (threadIdx.x == 0) S->local = total;
       return;
     }
-    if (pv) {
+    if (P2P) { // (its own instantiation: the single-rank step stays as small as it was)
       __syncthreads(); // lds16 is reused
       total = p2p_allreduce_sum(pv, total, seq, lds16, &S->p2p_error);
       if (S->p2p_error) { // uniform: written before the barriers inside

@@ -133,7 +133,7 @@ static bool spmv_can_fuse_dot(const sb_cg* s)
 template <int MODE> static void scalar_launch(sb_cg* s, int defer_x = 0)
 {
   if (multi_rank() && g.p2pOn) { // local reduce, in-kernel all-reduce and scalar step in ONE launch
-    hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
+    hipLaunchKernelGGL((cg_scalar_k<MODE, true, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
         s->S, s->rr_hist, s->pAp_hist, 0, defer_x, (const P2PView*)g.p2pView, ++g.p2pSeq);
     HIP_CHECK(hipGetLastError());
     return;
