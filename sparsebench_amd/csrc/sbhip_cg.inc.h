@@ -188,21 +188,21 @@ static void loop_body(sb_cg* s, int k)
   static const bool overlapHalo = !(getenv("SB_HALO_OVERLAP") && atoi(getenv("SB_HALO_OVERLAP")) == 0);
   if (overlapHalo && multi_rank() && s->halo && spmv_can_fuse_dot(s) && spmv_can_split(s->A)) {
     // :122-126 with the halo exchange hidden behind the interior tiles: the exchange (pack,
-    // send/recv into the tail of p) runs on a second stream while the tiles that touch no
-    // halo column are multiplied; the halo-touching tiles follow.  RCCL calls on the one
-    // communicator stay ordered: the exchange is complete (event) before anything later.
-    if (g.hasXport) halo_exchange(s->halo, s->p, stop); // host-mediated: synchronous anyway
-    else {
-      HIP_CHECK(hipEventRecord(g.evFork, g.stream));
-      HIP_CHECK(hipStreamWaitEvent(g.stream2, g.evFork, 0));
-      halo_exchange(s->halo, s->p, stop, g.stream2);
-      HIP_CHECK(hipEventRecord(g.evJoin, g.stream2));
-    }
+    // send/recv into the tail of p) AND the few halo-touching tiles that need it run on a
+    // second stream while the tiles that touch no halo column are multiplied on the main one;
+    // the scalar step waits for both.  RCCL calls on the one communicator stay ordered: the
+    // exchange is complete (event) before anything later on the main stream.
     mark(s, R_COMM);
     spmv_event(s);
+    // (a host-mediated transport blocks the host inside halo_exchange, so nothing overlaps
+    //  there, but the fork / join is the same code)
+    HIP_CHECK(hipEventRecord(g.evFork, g.stream));
+    HIP_CHECK(hipStreamWaitEvent(g.stream2, g.evFork, 0));
+    halo_exchange(s->halo, s->p, stop, g.stream2);
+    launch_spmv(s->A, s->p, s->Ap, s->partials, stop, 2, g.stream2);
+    HIP_CHECK(hipEventRecord(g.evJoin, g.stream2));
     launch_spmv(s->A, s->p, s->Ap, s->partials, stop, 1);
-    if (!g.hasXport) HIP_CHECK(hipStreamWaitEvent(g.stream, g.evJoin, 0));
-    launch_spmv(s->A, s->p, s->Ap, s->partials, stop, 2);
+    HIP_CHECK(hipStreamWaitEvent(g.stream, g.evJoin, 0));
     spmv_event(s);
     mark(s, R_SPMVM);
     goto alpha_step;

@@ -19,16 +19,16 @@ static bool spmv_can_split(const sb_matrix* m)
   return spmv_uses_patterns(m) && pm->patInterior > 0 && pm->patInterior < (pm->nChunks + 3) / 4;
 }
 static void launch_pat(const sb_matrix* pm, bool skipPad, const double* x, double* y, double* dotPartials,
-    const int* stop, int part);
+    const int* stop, int part, hipStream_t stream);
 
 static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* dotPartials,
-    const int* stop, int part = 0)
+    const int* stop, int part = 0, hipStream_t stream = nullptr)
 {
   const bool dot = dotPartials != nullptr;
   if (m->nr == 0) return;
   if (part != 0 && !spmv_can_split(m)) SB_FATAL("this SpMV kernel cannot be launched in parts");
   if (m->fmt == 0 && spmv_uses_patterns(m)) {
-    launch_pat(m->mirror, true, x, y, dotPartials, stop, part);
+    launch_pat(m->mirror, true, x, y, dotPartials, stop, part, stream ? stream : g.stream);
   } else if (m->fmt == 0) {
     if (dot) SB_FATAL("fused dot needs the pattern kernel (SCS C=64, or CRS through its mirror)");
     const uint32_t per = (m->nRowBlocks + 7) / 8;
@@ -47,7 +47,7 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
     const uint32_t per     = g_scs_xcd ? (nBlocks + 7) / 8 : 0;
     dim3 grid(g_scs_xcd ? per * 8 : nBlocks), block(256);
     if (m->usePacked == 3) {
-      launch_pat(m, false, x, y, dotPartials, stop, part);
+      launch_pat(m, false, x, y, dotPartials, stop, part, stream ? stream : g.stream);
     } else if (m->usePacked == 2) {
       const size_t shmem = (256 + (size_t)m->ldsWindow) * sizeof(double);
 #define LDS_LAUNCH(DI, DO)                                                                                   \
@@ -102,7 +102,7 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
 }
 
 static void launch_pat(const sb_matrix* pm, bool skipPad, const double* x, double* y, double* dotPartials,
-    const int* stop, int part)
+    const int* stop, int part, hipStream_t stream)
 {
   const bool dot         = dotPartials != nullptr;
   const uint32_t nBlocks = (pm->nChunks + 3) / 4;
@@ -113,7 +113,7 @@ static void launch_pat(const sb_matrix* pm, bool skipPad, const double* x, doubl
   const uint32_t pper  = g_scs_xcd ? (count + 7) / 8 : 0;
   const dim3 pgrid(g_scs_xcd ? pper * 8 : count), block(256);
 #define PAT_LAUNCH(DO, SK)                                                                                       \
-  hipLaunchKernelGGL((spmv_scs64_pat<DO, SK>), pgrid, block, shmem, g.stream, pm->tileHdrs, pm->jcodes, pm->rowBase, \
+  hipLaunchKernelGGL((spmv_scs64_pat<DO, SK>), pgrid, block, shmem, stream, pm->tileHdrs, pm->jcodes, pm->rowBase, \
       pm->classDict, pm->rowPats, pm->excRows, pm->tileSegs, x, y, pm->nr, pm->nChunks, first, count, pper,      \
       pm->padCol, pm->patDict, pm->patExcLds, dotPartials, stop)
   if (skipPad) {
