@@ -162,6 +162,23 @@ static void spmv_event(sb_cg* s)
   HIP_CHECK(hipEventRecord(s->spmvEv[s->spmvEvUsed++], g.stream));
 }
 
+// Ap = A p and the level-0 partials of p.Ap (src/CGSolver.c:123-125): fused into the SpMV epilogue
+// where the kernel is wave-per-chunk, otherwise SpMV then a dot pass
+static void spmv_and_pAp(sb_cg* s, const int* stop)
+{
+  const uint32_t n = s->nr;
+  if (spmv_can_fuse_dot(s)) {
+    launch_spmv(s->A, s->p, s->Ap, s->partials, stop);
+    spmv_event(s);
+    mark(s, R_SPMVM);
+  } else {
+    launch_spmv(s->A, s->p, s->Ap, nullptr, stop);
+    spmv_event(s);
+    mark(s, R_SPMVM);
+    launch_dot_spans(0, n, s->p, s->Ap, nullptr, nullptr, s->S, s->partials, stop);
+  }
+}
+
 // one loop body of solveCG (src/CGSolver.c:108-128).  Fused path: the r.r partials of the
 // NEXT body come out of this body's x/r update, and its beta + loop test are taken right
 // after it, so a body is: p update | SpMV (+p.Ap partials) | alpha | x/r update (+r.r
@@ -205,22 +222,12 @@ static void loop_body(sb_cg* s, int k)
     HIP_CHECK(hipStreamWaitEvent(g.stream, g.evJoin, 0));
     spmv_event(s);
     mark(s, R_SPMVM);
-    goto alpha_step;
-  }
-  halo_exchange(s->halo, s->p, stop); // :122
-  mark(s, R_COMM);
-  spmv_event(s);
-  if (spmv_can_fuse_dot(s)) { // Ap = A p, alpha = rtrans / p.Ap (:123-126)
-    launch_spmv(s->A, s->p, s->Ap, s->partials, stop);
-    spmv_event(s);
-    mark(s, R_SPMVM);
   } else {
-    launch_spmv(s->A, s->p, s->Ap, nullptr, stop);
+    halo_exchange(s->halo, s->p, stop); // :122
+    mark(s, R_COMM);
     spmv_event(s);
-    mark(s, R_SPMVM);
-    launch_dot_spans(0, n, s->p, s->Ap, nullptr, nullptr, s->S, s->partials, stop);
+    spmv_and_pAp(s, stop);
   }
-alpha_step:
   scalar_launch<2>(s);
   mark(s, R_DDOT);
   if (s->fused) { // r -= alpha Ap (:128) + next r.r, beta, loop test; x += alpha p (:127) is owed
