@@ -241,15 +241,32 @@ static void build_lds_windows(sb_matrix* m, const uint32_t* chunkPtr, const uint
   m->usePacked = 2; // 2: packed stream + x window in LDS
 }
 
+// ---- levels 4 and 5 (pack.hip.h): host side ---------------------------------------------------
 // Level 4: one byte per element naming a (value, slot delta) pair of the tile's class;
-// level 5: per chunk one shared row pattern + the odd lanes (pack.hip.h).  Needs the value
-// dictionary and the LDS windows.  SB_PACK=4 stops at level 4 (every chunk per-lane).
-static void build_patterns(sb_matrix* m)
+// level 5: per chunk one shared row pattern + the odd lanes.  Needs the value dictionary and the
+// LDS windows.  SB_PACK=4 stops at level 4 (every chunk per-lane).
+struct PatternPlan { // working set of build_patterns
+  uint32_t nTiles = 0;
+  // level 4
+  std::vector<std::vector<uint32_t>> classes; // sorted pair keys of every class
+  std::vector<uint32_t> tileClass;
+  std::vector<PatEntry> classDict; // [class][256]
+  std::vector<PackMeta> meta;
+  uint64_t groups = 0; // code groups (4 columns) of the whole matrix
+  // level 5
+  std::vector<uint32_t> exc;      // [chunk][2] exception-lane mask
+  std::vector<PatEntry> rowPats;  // shared dominant row patterns, back to back
+  size_t nRowPats = 0;
+  std::vector<uint32_t> chunkOff, chunkFlags, chunkPat, tileExcStart, tileExcCount;
+  uint64_t words = 0, excEntries = 0; // L code words / U exception entries in total
+  uint32_t excLds = 0;                // most exception entries of one tile
+  bool anyL       = false;
+};
+
+// pairs of every tile (device) -> classes of <= PAT_MAX pairs -> class tables; false: level 3 stays
+static bool pattern_classes(sb_matrix* m, PatternPlan& P)
 {
-  if (m->usePacked != 2 || m->nDict <= 0) return;
-  const char* env = getenv("SB_PACK");
-  if ((env ? atoi(env) : 4) < 4) return;
-  const uint32_t nTiles = (m->nChunks + 3) / 4;
+  const uint32_t nTiles = P.nTiles;
   uint32_t *dCount = nullptr, *dKeys = nullptr;
   HIP_CHECK(hipMalloc(&m->rowBase, (size_t)m->nChunks * 64 * sizeof(uint16_t) + 16));
   HIP_CHECK(hipMalloc(&dCount, (size_t)nTiles * sizeof(uint32_t)));
@@ -260,17 +277,16 @@ static void build_patterns(sb_matrix* m)
   std::vector<uint32_t> count(nTiles), keys((size_t)nTiles * 256);
   sb_d2h(count.data(), dCount, count.size() * sizeof(uint32_t));
   sb_d2h(keys.data(), dKeys, keys.size() * sizeof(uint32_t));
-  HIP_CHECK(hipFree(dCount));
-  HIP_CHECK(hipFree(dKeys));
-  auto giveUp = [&]() { sb_free(m->rowBase), m->rowBase = nullptr; };
+  sb_free(dCount), sb_free(dKeys);
   for (uint32_t t = 0; t < nTiles; t++)
-    if (count[t] > PAT_MAX) return giveUp();
-  // tiles -> classes of <= PAT_MAX pairs: a class that already holds the tile's pairs,
-  // else the first class the pairs still fit into, else a new class
-  std::vector<std::vector<uint32_t>> classes;
-  std::vector<uint32_t> tileClass(nTiles, 0), merged;
+    if (count[t] > PAT_MAX) return false;
+  // tiles -> classes: a class that already holds the tile's pairs, else the first class the
+  // pairs still fit into, else a new class
+  P.tileClass.assign(nTiles, 0);
+  std::vector<uint32_t> merged;
   const size_t maxClasses = std::max<size_t>(64, nTiles / 4);
   uint32_t lastClass = 0;
+  auto& classes = P.classes;
   for (uint32_t t = 0; t < nTiles; t++) {
     uint32_t* k = keys.data() + (size_t)t * 256;
     std::sort(k, k + count[t]);
@@ -285,141 +301,101 @@ static void build_patterns(sb_matrix* m)
       if (merged.size() <= PAT_MAX) classes[c] = merged, found = (int)c;
     }
     if (found < 0) {
-      if (classes.size() >= maxClasses) return giveUp(); // no repeating patterns: not worth the tables
+      if (classes.size() >= maxClasses) return false; // no repeating patterns: not worth the tables
       classes.emplace_back(k, k + count[t]);
       found = (int)classes.size() - 1;
     }
-    tileClass[t] = lastClass = (uint32_t)found;
+    P.tileClass[t] = lastClass = (uint32_t)found;
   }
   if (classes.empty()) classes.emplace_back();
+  P.meta.resize(m->nChunks);
+  sb_d2h(P.meta.data(), m->pmeta, P.meta.size() * sizeof(PackMeta));
+  for (const PackMeta& pm : P.meta)
+    if ((pm.info & 0x7FFFFFFFu) >= PAT_NOPAD) return false; // chunk width collides with the header's flag bits
+  P.groups = (uint64_t)P.meta.back().grp + ((P.meta.back().info & 0x7FFFFFFFu) + 3u) / 4u;
   std::vector<double> dict(256);
   sb_d2h(dict.data(), m->pdict, 256 * sizeof(double));
-  std::vector<uint32_t> classKeys(classes.size() * 256, PAT_EMPTY);
-  std::vector<PatEntry> classDict(classes.size() * 256, PatEntry{ 0.0, 0, 0u });
+  P.classDict.assign(classes.size() * 256, PatEntry{ 0.0, 0, 0u });
   for (size_t c = 0; c < classes.size(); c++)
     for (size_t i = 0; i < classes[c].size(); i++) {
-      const uint32_t key       = classes[c][i];
-      classKeys[c * 256 + i]   = key;
-      PatEntry& e              = classDict[c * 256 + i];
-      e.v                      = dict[key & 255u];
+      const uint32_t key = classes[c][i];
+      PatEntry& e        = P.classDict[c * 256 + i];
+      e.v                = dict[key & 255u];
       if (key & PAT_ABS) e.off8 = 0u, e.m = 0u; // padding: slot 0
       else e.off8 = (uint32_t)(8 * ((int32_t)((key >> 8) & 0xFFFFu) - 32768)), e.m = 1u; // 8 * (slot - rowBase), mod 2^32
     }
-  uint32_t* dClassKeys = (uint32_t*)upload(classKeys.data(), classKeys.size() * sizeof(uint32_t));
-  m->tileClass         = (uint32_t*)upload(tileClass.data(), tileClass.size() * sizeof(uint32_t));
-  m->classDict         = (PatEntry*)upload(classDict.data(), classDict.size() * sizeof(PatEntry));
-  std::vector<PackMeta> meta(m->nChunks);
-  sb_d2h(meta.data(), m->pmeta, meta.size() * sizeof(PackMeta));
-  const uint64_t groups = (uint64_t)meta.back().grp + ((meta.back().info & 0x7FFFFFFFu) + 3u) / 4u;
-  for (const PackMeta& pm : meta)
-    if ((pm.info & 0x7FFFFFFFu) >= PAT_NOPAD) { // chunk width collides with the header's flag bits
-      sb_free(dClassKeys), sb_free(m->tileClass), sb_free(m->classDict);
-      m->tileClass = nullptr, m->classDict = nullptr;
-      return giveUp();
-    }
-  uint32_t* lanes = nullptr; // per-lane code words, group-major (the L form of every chunk)
-  HIP_CHECK(hipMalloc(&lanes, (size_t)groups * 256 + 1024));
-  hipLaunchKernelGGL(pat_encode_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, m->pslots, m->pcodes,
-      m->nChunks, m->rowBase, m->tileClass, dClassKeys, lanes);
-  HIP_CHECK(hipGetLastError());
-  // Level 5 (row patterns): dominant code sequence and exception lanes of every chunk
-  const bool wantRows = (env ? atoi(env) : 5) >= 5;
-  uint32_t *dDom = nullptr, *dExc = nullptr;
-  HIP_CHECK(hipMalloc(&dDom, (size_t)groups * sizeof(uint32_t) + 16));
-  HIP_CHECK(hipMalloc(&dExc, (size_t)m->nChunks * 2 * sizeof(uint32_t)));
-  hipLaunchKernelGGL(pat_dominant_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dDom,
-      dExc);
-  HIP_CHECK(hipGetLastError());
-  std::vector<uint32_t> dom(groups ? groups : 1), exc((size_t)m->nChunks * 2);
-  sb_d2h(dom.data(), dDom, (size_t)groups * sizeof(uint32_t));
-  sb_d2h(exc.data(), dExc, exc.size() * sizeof(uint32_t));
-  HIP_CHECK(hipFree(dDom));
-  // chunk by chunk: U (row pattern + expanded exception lanes) or L (code words of all 64
-  // lanes); row patterns are shared between chunks (key: the expanded entries).  A tile's
-  // exception entries are staged in LDS, so a tile with too many of them stays L.
+  return true;
+}
+
+// chunk by chunk: U (row pattern + expanded exception lanes) or L (code words of all 64 lanes); row
+// patterns are shared between chunks (key: the expanded entries).  A tile's exception entries are
+// staged in LDS, so a tile with too many of them stays L.  `dom`: dominant code words per group.
+static void pattern_rows(sb_matrix* m, PatternPlan& P, const std::vector<uint32_t>& dom, bool wantRows)
+{
   const size_t maxPatEntries = 1u << 20; // 16 MiB of pattern rows at most
-  std::vector<PatEntry> rowPats;
   std::unordered_map<std::string, uint32_t> patIndex;
-  std::vector<uint32_t> chunkOff(m->nChunks), chunkFlags(m->nChunks), chunkPat(m->nChunks, 0);
-  std::vector<uint32_t> tileExcStart(nTiles, 0), tileExcCount(nTiles, 0);
+  P.chunkOff.assign(m->nChunks, 0), P.chunkFlags.assign(m->nChunks, 0), P.chunkPat.assign(m->nChunks, 0);
+  P.tileExcStart.assign(P.nTiles, 0), P.tileExcCount.assign(P.nTiles, 0);
   std::vector<PatEntry> row;
-  uint64_t words = 0, excEntries = 0;
-  uint32_t excLds = 0;
-  bool anyL       = false;
   m->nUniformChunks = 0;
   auto n_exc = [&](uint32_t c) {
-    return (uint32_t)__builtin_popcount(exc[2 * (size_t)c]) + (uint32_t)__builtin_popcount(exc[2 * (size_t)c + 1]);
+    return (uint32_t)__builtin_popcount(P.exc[2 * (size_t)c]) + (uint32_t)__builtin_popcount(P.exc[2 * (size_t)c + 1]);
   };
-  for (uint32_t t = 0; t < nTiles; t++) {
+  for (uint32_t t = 0; t < P.nTiles; t++) {
     const uint32_t c0 = t * 4, c1 = std::min(c0 + 4, m->nChunks);
     uint64_t tileExc = 0;
     bool tileOk      = wantRows;
     for (uint32_t c = c0; c < c1 && tileOk; c++) {
-      const uint32_t len = meta[c].info & 0x7FFFFFFFu;
+      const uint32_t len = P.meta[c].info & 0x7FFFFFFFu;
       if (len == 0 || n_exc(c) > PAT_EXC_MAX) continue; // this chunk will be L
       tileExc += (uint64_t)n_exc(c) * len;
     }
     if (tileExc > PAT_EXC_LDS_MAX) tileOk = false;
-    tileExcStart[t] = (uint32_t)excEntries;
+    P.tileExcStart[t] = (uint32_t)P.excEntries;
     for (uint32_t c = c0; c < c1; c++) {
-      const uint32_t len = meta[c].info & 0x7FFFFFFFu, ng = (len + 3u) / 4u, nExc = n_exc(c);
+      const uint32_t len = P.meta[c].info & 0x7FFFFFFFu, ng = (len + 3u) / 4u, nExc = n_exc(c);
       bool uni = tileOk && len > 0 && nExc <= PAT_EXC_MAX, nopad = true;
       if (uni) {
         row.resize(len);
-        const PatEntry* cd = classDict.data() + (size_t)tileClass[t] * 256;
+        const PatEntry* cd = P.classDict.data() + (size_t)P.tileClass[t] * 256;
         for (uint32_t j = 0; j < len; j++) {
-          row[j] = cd[(dom[meta[c].grp + j / 4] >> (8u * (j & 3u))) & 255u];
+          row[j] = cd[(dom[P.meta[c].grp + j / 4] >> (8u * (j & 3u))) & 255u];
           nopad  = nopad && row[j].m == 1u;
         }
         std::string key((const char*)row.data(), row.size() * sizeof(PatEntry));
         auto it = patIndex.find(key);
-        if (it != patIndex.end()) chunkPat[c] = it->second;
-        else if (rowPats.size() + len <= maxPatEntries) {
-          chunkPat[c] = (uint32_t)rowPats.size();
-          patIndex.emplace(std::move(key), chunkPat[c]);
-          rowPats.insert(rowPats.end(), row.begin(), row.end());
+        if (it != patIndex.end()) P.chunkPat[c] = it->second;
+        else if (P.rowPats.size() + len <= maxPatEntries) {
+          P.chunkPat[c] = (uint32_t)P.rowPats.size();
+          patIndex.emplace(std::move(key), P.chunkPat[c]);
+          P.rowPats.insert(P.rowPats.end(), row.begin(), row.end());
         } else uni = false; // table full
       }
       if (uni) {
-        chunkOff[c]   = (uint32_t)excEntries;
-        chunkFlags[c] = len | PAT_UNIFORM | (nopad ? PAT_NOPAD : 0u);
-        excEntries += (uint64_t)nExc * len;
-        tileExcCount[t] += nExc * len;
+        P.chunkOff[c]   = (uint32_t)P.excEntries;
+        P.chunkFlags[c] = len | PAT_UNIFORM | (nopad ? PAT_NOPAD : 0u);
+        P.excEntries += (uint64_t)nExc * len;
+        P.tileExcCount[t] += nExc * len;
         m->nUniformChunks++;
       } else {
-        chunkOff[c]   = (uint32_t)words;
-        chunkFlags[c] = len;
-        words += (uint64_t)ng * 64u;
-        anyL = anyL || len > 0;
+        P.chunkOff[c]   = (uint32_t)P.words;
+        P.chunkFlags[c] = len;
+        P.words += (uint64_t)ng * 64u;
+        P.anyL = P.anyL || len > 0;
       }
     }
-    excLds = std::max(excLds, tileExcCount[t]);
+    P.excLds = std::max(P.excLds, P.tileExcCount[t]);
   }
-  if (words > 0xFFFFFFFFull || excEntries > 0xFFFFFFFFull) {
-    sb_free(lanes), sb_free(dExc), sb_free(dClassKeys);
-    sb_free(m->classDict), m->classDict = nullptr;
-    return giveUp();
-  }
-  uint32_t* dOff   = (uint32_t*)upload(chunkOff.data(), chunkOff.size() * sizeof(uint32_t));
-  uint32_t* dFlags = (uint32_t*)upload(chunkFlags.data(), chunkFlags.size() * sizeof(uint32_t));
-  const size_t streamBytes = (size_t)words * sizeof(uint32_t) + 1024;          // slack: clamped reads
-  const size_t excBytes    = ((size_t)excEntries + 520) * sizeof(PatEntry);     // slack: 2 x 256 unconditional reads
-  HIP_CHECK(hipMalloc(&m->jcodes, streamBytes));
-  HIP_CHECK(hipMalloc(&m->excRows, excBytes));
-  HIP_CHECK(hipMemsetAsync(m->jcodes, 0, streamBytes, g.stream));
-  HIP_CHECK(hipMemsetAsync(m->excRows, 0, excBytes, g.stream));
-  hipLaunchKernelGGL(pat_compact_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dOff,
-      dFlags, dExc, m->rowBase, m->tileClass, m->classDict, m->jcodes, m->excRows);
-  HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipStreamSynchronize(g.stream));
-  sb_free(lanes), sb_free(dExc), sb_free(dOff), sb_free(dFlags), sb_free(dClassKeys);
-  if (rowPats.empty()) rowPats.push_back(PatEntry{ 0.0, 0u, 0u });
-  m->rowPats     = (PatEntry*)upload(rowPats.data(), rowPats.size() * sizeof(PatEntry));
-  m->nRowPats    = (uint32_t)patIndex.size();
-  m->nPatClasses = (uint32_t)classes.size();
-  m->patDict     = anyL ? 256u : 0u;
-  m->patExcLds   = excLds;
-  // one header per tile: class, chunk positions / widths / row patterns, the first segments
+  P.nRowPats = patIndex.size();
+  if (P.rowPats.empty()) P.rowPats.push_back(PatEntry{ 0.0, 0u, 0u });
+}
+
+// one header per tile: class, chunk positions / widths / row patterns, the first segments; tiles
+// whose window holds a halo column (>= nr) go last, so that the interior part of the product does
+// not have to wait for the halo exchange (loop_body).  Returns the number of segments.
+static size_t pattern_headers(sb_matrix* m, const PatternPlan& P)
+{
+  const uint32_t nTiles = P.nTiles;
   std::vector<uint32_t> segPtr(nTiles + 1);
   sb_d2h(segPtr.data(), m->tileSegPtr, segPtr.size() * sizeof(uint32_t));
   const size_t nSegs = segPtr[nTiles];
@@ -430,13 +406,13 @@ static void build_patterns(sb_matrix* m)
     TileHdr& h = hdrs[t];
     memset(&h, 0, sizeof h);
     h.tile = t;
-    h.cls = tileClass[t], h.nseg = segPtr[t + 1] - segPtr[t], h.segPtr = segPtr[t], h.win = 1;
-    h.excStart = tileExcStart[t], h.excCount = tileExcCount[t];
+    h.cls = P.tileClass[t], h.nseg = segPtr[t + 1] - segPtr[t], h.segPtr = segPtr[t], h.win = 1;
+    h.excStart = P.tileExcStart[t], h.excCount = P.tileExcCount[t];
     for (uint32_t w = 0; w < 4; w++) {
       const uint32_t c = t * 4 + w;
       if (c >= m->nChunks) continue;
-      h.off[w] = chunkOff[c], h.len[w] = chunkFlags[c], h.rowPat[w] = chunkPat[c];
-      if (chunkFlags[c] & PAT_UNIFORM) h.exc[w][0] = exc[2 * (size_t)c], h.exc[w][1] = exc[2 * (size_t)c + 1];
+      h.off[w] = P.chunkOff[c], h.len[w] = P.chunkFlags[c], h.rowPat[w] = P.chunkPat[c];
+      if (P.chunkFlags[c] & PAT_UNIFORM) h.exc[w][0] = P.exc[2 * (size_t)c], h.exc[w][1] = P.exc[2 * (size_t)c + 1];
     }
     for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++) h.seg[s][1] = 0xFFFFFFFFu;
     h.winInline = 1;
@@ -456,8 +432,6 @@ static void build_patterns(sb_matrix* m)
     }
     h.flags = simple ? PAT_SIMPLE_WINDOW : 0u;
   }
-  // tiles whose window holds a halo column (>= nr) go last: the interior part of the product
-  // does not have to wait for the halo exchange (loop_body)
   m->patInterior = nTiles;
   if (m->nc > m->nr) {
     auto touches_halo = [&](const TileHdr& h) {
@@ -474,18 +448,78 @@ static void build_patterns(sb_matrix* m)
   if (getenv("SB_PACK_REPORT")) {
     size_t nSimple = 0;
     for (const TileHdr& h : hdrs) nSimple += h.flags & PAT_SIMPLE_WINDOW;
-    fprintf(stderr, "sbhip pack: %u tiles (%u interior, %zu simple windows, max %u entries), %u classes, %u/%u U chunks, "
+    fprintf(stderr, "sbhip pack: %u tiles (%u interior, %zu simple windows, max %u entries), %zu classes, %u/%u U chunks, "
                     "%zu row patterns (%zu entries), %llu exception entries (max %u per tile), %llu code words\n",
-        nTiles, m->patInterior, nSimple, m->ldsWindow, m->nPatClasses, m->nUniformChunks, m->nChunks, patIndex.size(),
-        rowPats.size(), (unsigned long long)excEntries, excLds, (unsigned long long)words);
+        nTiles, m->patInterior, nSimple, m->ldsWindow, P.classes.size(), m->nUniformChunks, m->nChunks, P.nRowPats,
+        P.rowPats.size(), (unsigned long long)P.excEntries, P.excLds, (unsigned long long)P.words);
   }
-  m->patBytes = (double)words * 4.0 + 16.0 * (double)excEntries + 2.0 * 64.0 * m->nChunks + 16.0 * nSegs +
-                (double)sizeof(TileHdr) * nTiles + (anyL ? 4096.0 * classes.size() : 0.0) + 16.0 * rowPats.size();
+  return nSegs;
+}
+
+static void build_patterns(sb_matrix* m)
+{
+  if (m->usePacked != 2 || m->nDict <= 0) return;
+  const char* env = getenv("SB_PACK");
+  if ((env ? atoi(env) : 4) < 4) return;
+  PatternPlan P;
+  P.nTiles = (m->nChunks + 3) / 4;
+  if (!pattern_classes(m, P)) { // the matrix stays at level 3
+    sb_free(m->rowBase), m->rowBase = nullptr;
+    return;
+  }
+  // per-lane code words of every chunk (its L form), then the dominant sequence + odd lanes
+  std::vector<uint32_t> classKeys(P.classes.size() * 256, PAT_EMPTY);
+  for (size_t c = 0; c < P.classes.size(); c++) std::copy(P.classes[c].begin(), P.classes[c].end(), classKeys.begin() + c * 256);
+  uint32_t* dClassKeys = (uint32_t*)upload(classKeys.data(), classKeys.size() * sizeof(uint32_t));
+  m->tileClass         = (uint32_t*)upload(P.tileClass.data(), P.tileClass.size() * sizeof(uint32_t));
+  m->classDict         = (PatEntry*)upload(P.classDict.data(), P.classDict.size() * sizeof(PatEntry));
+  uint32_t *lanes = nullptr, *dDom = nullptr, *dExc = nullptr;
+  HIP_CHECK(hipMalloc(&lanes, (size_t)P.groups * 256 + 1024));
+  HIP_CHECK(hipMalloc(&dDom, (size_t)P.groups * sizeof(uint32_t) + 16));
+  HIP_CHECK(hipMalloc(&dExc, (size_t)m->nChunks * 2 * sizeof(uint32_t)));
+  hipLaunchKernelGGL(pat_encode_k, dim3(P.nTiles), dim3(256), 0, g.stream, m->pmeta, m->pslots, m->pcodes,
+      m->nChunks, m->rowBase, m->tileClass, dClassKeys, lanes);
+  hipLaunchKernelGGL(pat_dominant_k, dim3(P.nTiles), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dDom,
+      dExc);
+  HIP_CHECK(hipGetLastError());
+  std::vector<uint32_t> dom(P.groups ? P.groups : 1);
+  P.exc.resize((size_t)m->nChunks * 2);
+  sb_d2h(dom.data(), dDom, (size_t)P.groups * sizeof(uint32_t));
+  sb_d2h(P.exc.data(), dExc, P.exc.size() * sizeof(uint32_t));
+  sb_free(dDom), sb_free(dClassKeys);
+  pattern_rows(m, P, dom, (env ? atoi(env) : 5) >= 5);
+  if (P.words > 0xFFFFFFFFull || P.excEntries > 0xFFFFFFFFull) { // positions are 32-bit
+    sb_free(lanes), sb_free(dExc), sb_free(m->classDict), sb_free(m->tileClass), sb_free(m->rowBase);
+    m->classDict = nullptr, m->tileClass = nullptr, m->rowBase = nullptr;
+    return;
+  }
+  // final form: L code words / expanded exception rows of the U chunks
+  uint32_t* dOff   = (uint32_t*)upload(P.chunkOff.data(), P.chunkOff.size() * sizeof(uint32_t));
+  uint32_t* dFlags = (uint32_t*)upload(P.chunkFlags.data(), P.chunkFlags.size() * sizeof(uint32_t));
+  const size_t streamBytes = (size_t)P.words * sizeof(uint32_t) + 1024;       // slack: clamped reads
+  const size_t excBytes    = ((size_t)P.excEntries + 520) * sizeof(PatEntry); // slack: 2 x 256 unconditional reads
+  HIP_CHECK(hipMalloc(&m->jcodes, streamBytes));
+  HIP_CHECK(hipMalloc(&m->excRows, excBytes));
+  HIP_CHECK(hipMemsetAsync(m->jcodes, 0, streamBytes, g.stream));
+  HIP_CHECK(hipMemsetAsync(m->excRows, 0, excBytes, g.stream));
+  hipLaunchKernelGGL(pat_compact_k, dim3(P.nTiles), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dOff,
+      dFlags, dExc, m->rowBase, m->tileClass, m->classDict, m->jcodes, m->excRows);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  sb_free(lanes), sb_free(dExc), sb_free(dOff), sb_free(dFlags);
+  m->rowPats     = (PatEntry*)upload(P.rowPats.data(), P.rowPats.size() * sizeof(PatEntry));
+  m->nRowPats    = (uint32_t)P.nRowPats;
+  m->nPatClasses = (uint32_t)P.classes.size();
+  m->patDict     = P.anyL ? 256u : 0u;
+  m->patExcLds   = P.excLds;
+  const size_t nSegs = pattern_headers(m, P);
+  m->patBytes = (double)P.words * 4.0 + 16.0 * (double)P.excEntries + 2.0 * 64.0 * m->nChunks + 16.0 * nSegs +
+                (double)sizeof(TileHdr) * P.nTiles + (P.anyL ? 4096.0 * P.classes.size() : 0.0) + 16.0 * P.rowPats.size();
   // Default kernel: the pattern kernel once the matrix is more than one round of resident
   // workgroups (8 per CU); below that everything is one dependent-latency chain and the
   // level-3 kernel's is shorter (64^3: 46.7k vs 43.2k CG it/s; 96^3: 22.8k vs 26.3k).
   // sb_matrix_use_packed(m, 3) selects it regardless.
-  m->usePacked = nTiles > (uint32_t)g.prop.multiProcessorCount * 8u ? 3 : 2;
+  m->usePacked = P.nTiles > (uint32_t)g.prop.multiProcessorCount * 8u ? 3 : 2;
 }
 
 sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, uint32_t nChunks,
