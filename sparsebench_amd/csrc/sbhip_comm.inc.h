@@ -62,6 +62,10 @@ int sb_comm_p2p_handle(unsigned char* handle_out)
   need_init();
   const char* env = getenv("SB_P2P");
   if (env && atoi(env) == 0) return 0;
+  // test hook: SB_P2P_FAIL_RANK=r makes rank r behave as if its buffer could not be exported, to
+  // exercise the collective fall-back decision (tests/test_gpu_multirank.py)
+  const char* failRank = getenv("SB_P2P_FAIL_RANK");
+  if (failRank && atoi(failRank) == g.rank) return 0;
   static_assert(sizeof(hipIpcMemHandle_t) <= SB_P2P_HANDLE_BYTES, "IPC handle size");
   if (!g.p2pBuf) {
     void* buf = nullptr; // fine-grained: coherent between GPUs while kernels are running

@@ -45,3 +45,18 @@ def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax, p2p):
     if p2p == "0":
         assert "P2P_ENABLED 0" in text
     print([ln for ln in text.splitlines() if "P2P_ENABLED" in ln or "in-kernel all-reduce" in ln][:3])
+
+
+def test_p2p_setup_failure_on_one_rank_falls_back_everywhere(gpu):
+    """the in-kernel all-reduce is enabled collectively: if ONE rank cannot export / map its buffer, every
+    rank must end up on the transport's all-reduce (no rank may wait in a kernel for a peer that never
+    writes), and the run is still bit-exact"""
+    env = dict(os.environ, OMP_NUM_THREADS="1", SB_P2P="1", SB_P2P_FAIL_RANK="1", SB_P2P_REPORT="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "gpu_multirank_worker.py"), "scs", "64", "1", "16", "60"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-4000:]
+    assert "GPU_MULTIRANK_OK scs 64 1 16 3" in text and "P2P_ENABLED 0" in text, text[-3000:]
+    assert text.count("in-kernel all-reduce over peer-mapped memory: off") == 3
