@@ -377,19 +377,29 @@ __global__ __launch_bounds__(256) void waxpby_sdev_k(uint32_t n, const double* x
 __global__ __launch_bounds__(256) void cg_update_p(uint32_t n, const double* __restrict__ r,
     double* p, double* x, const CgScalars* __restrict__ S, int which)
 {
-  if (S->stop) return;
-  const double beta     = which == 0 ? S->beta : 0.0;
-  const bool owed       = x != nullptr && which == 0 && S->x_pending;
-  const double alpha    = S->alpha;
   const uint32_t n2     = n >> 1;
   const uint32_t stride = gridDim.x * blockDim.x;
   const double2* r2     = reinterpret_cast<const double2*>(r);
   double2* p2           = reinterpret_cast<double2*>(p);
   double2* x2           = reinterpret_cast<double2*>(x);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-    double2 a = r2[i], b = which == 0 ? p2[i] : a, o;
+  uint32_t i            = blockIdx.x * blockDim.x + threadIdx.x;
+  // the first elements go in flight together with the control block (stop flag, beta, alpha)
+  // instead of behind it: clamped index, so the loads are unconditional
+  const uint32_t i0 = min(i, n2 ? n2 - 1u : 0u);
+  double2 a = { 0.0, 0.0 }, b = { 0.0, 0.0 }, xv = { 0.0, 0.0 };
+  if (n2) {
+    a = r2[i0];
+    b = which == 0 ? p2[i0] : a;
+    if (x != nullptr && which == 0) xv = x2[i0];
+  }
+  const int stopped  = S->stop;
+  const double beta  = which == 0 ? S->beta : 0.0;
+  const bool owed    = x != nullptr && which == 0 && S->x_pending;
+  const double alpha = S->alpha;
+  if (stopped) return;
+  for (; i < n2; i += stride) {
+    double2 o;
     if (owed) {
-      double2 xv = x2[i];
       xv.x = xv.x + alpha * b.x;
       xv.y = xv.y + alpha * b.y;
       x2[i] = xv;
@@ -397,11 +407,17 @@ __global__ __launch_bounds__(256) void cg_update_p(uint32_t n, const double* __r
     o.x = a.x + beta * b.x;
     o.y = a.y + beta * b.y;
     p2[i] = o;
+    const uint32_t nx = i + stride;
+    if (nx < n2) {
+      a = r2[nx];
+      b = which == 0 ? p2[nx] : a;
+      if (owed) xv = x2[nx];
+    }
   }
   if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const double b = which == 0 ? p[n - 1] : r[n - 1];
-    if (owed) x[n - 1] = x[n - 1] + alpha * b;
-    p[n - 1] = r[n - 1] + beta * b;
+    const double bb = which == 0 ? p[n - 1] : r[n - 1];
+    if (owed) x[n - 1] = x[n - 1] + alpha * bb;
+    p[n - 1] = r[n - 1] + beta * bb;
   }
 }
 
