@@ -445,13 +445,42 @@ __global__ __launch_bounds__(256) void dot_spans_k(uint32_t n, const double* a, 
     double* x, double* r, const CgScalars* __restrict__ S, double* __restrict__ partials,
     const int* __restrict__ stop)
 {
-  if (stop && *stop) return;
   const uint32_t lane   = threadIdx.x & 63u;
   const uint32_t nSpans = ((n + 255u) >> 8) * 2u; // whole 256-groups
   const uint32_t nWaves = gridDim.x * (blockDim.x >> 6);
+  uint32_t s            = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // OP 3 (once per CG iteration): two spans per step while both lie fully inside n, and the
+  // first pair's loads go in flight together with the stop flag / alpha instead of behind them
+  const bool pair0 = OP == 3 && s + nWaves < nSpans && (s + nWaves) * 128u + 128u <= n; // wave-uniform
+  double2 r0 = { 0.0, 0.0 }, a0 = r0, r1 = r0, a1 = r0;
+  if (pair0) {
+    const uint32_t e0 = s * 128u + lane * 2u, e1 = (s + nWaves) * 128u + lane * 2u;
+    r0 = *reinterpret_cast<const double2*>(r + e0), a0 = *reinterpret_cast<const double2*>(b + e0);
+    r1 = *reinterpret_cast<const double2*>(r + e1), a1 = *reinterpret_cast<const double2*>(b + e1);
+  }
+  if (stop && *stop) return;
   double alpha = 0.0, nalpha = 0.0;
   if (OP == 1 || OP == 3) alpha = S->alpha, nalpha = -alpha;
-  for (uint32_t s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < nSpans; s += nWaves) {
+  if (OP == 3) {
+    bool have = pair0;
+    while (have) {
+      const uint32_t e0 = s * 128u + lane * 2u, e1 = (s + nWaves) * 128u + lane * 2u;
+      r0.x = r0.x + nalpha * a0.x, r0.y = r0.y + nalpha * a0.y;
+      r1.x = r1.x + nalpha * a1.x, r1.y = r1.y + nalpha * a1.y;
+      *reinterpret_cast<double2*>(r + e0) = r0;
+      *reinterpret_cast<double2*>(r + e1) = r1;
+      const double t0 = butterfly32(r0.x * r0.x + r0.y * r0.y), t1 = butterfly32(r1.x * r1.x + r1.y * r1.y);
+      if ((lane & 31u) == 0) partials[s * 2u + (lane >> 5)] = t0, partials[(s + nWaves) * 2u + (lane >> 5)] = t1;
+      s += 2u * nWaves;
+      have = s + nWaves < nSpans && (s + nWaves) * 128u + 128u <= n;
+      if (have) {
+        const uint32_t f0 = s * 128u + lane * 2u, f1 = (s + nWaves) * 128u + lane * 2u;
+        r0 = *reinterpret_cast<const double2*>(r + f0), a0 = *reinterpret_cast<const double2*>(b + f0);
+        r1 = *reinterpret_cast<const double2*>(r + f1), a1 = *reinterpret_cast<const double2*>(b + f1);
+      }
+    }
+  }
+  for (; s < nSpans; s += nWaves) { // (OP 3: what the paired loop left over)
     const uint32_t e = s * 128u + lane * 2u;
     double t         = 0.0;
     if (OP == 0) {
