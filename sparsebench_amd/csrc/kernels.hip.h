@@ -383,36 +383,40 @@ __global__ __launch_bounds__(256) void cg_update_p(uint32_t n, const double* __r
   double2* p2           = reinterpret_cast<double2*>(p);
   double2* x2           = reinterpret_cast<double2*>(x);
   uint32_t i            = blockIdx.x * blockDim.x + threadIdx.x;
-  // the first elements go in flight together with the control block (stop flag, beta, alpha)
-  // instead of behind it: clamped index, so the loads are unconditional
-  const uint32_t i0 = min(i, n2 ? n2 - 1u : 0u);
-  double2 a = { 0.0, 0.0 }, b = { 0.0, 0.0 }, xv = { 0.0, 0.0 };
-  if (n2) {
-    a = r2[i0];
-    b = which == 0 ? p2[i0] : a;
-    if (x != nullptr && which == 0) xv = x2[i0];
-  }
+  const bool useX       = x != nullptr && which == 0;
+  // Two elements (i, i + stride) per step, and the first pair goes in flight together with
+  // the control block (stop flag, beta, alpha) instead of behind it: clamped indices, so the
+  // loads are unconditional.
+  const uint32_t last = n2 ? n2 - 1u : 0u;
+  double2 a0 = { 0.0, 0.0 }, b0 = a0, x0 = a0, a1 = a0, b1 = a0, x1 = a0;
+  auto load = [&](uint32_t j, double2& a, double2& b, double2& xv) {
+    a = r2[j];
+    b = which == 0 ? p2[j] : a;
+    if (useX) xv = x2[j];
+  };
+  if (n2) load(min(i, last), a0, b0, x0), load(min(i + stride, last), a1, b1, x1);
   const int stopped  = S->stop;
   const double beta  = which == 0 ? S->beta : 0.0;
-  const bool owed    = x != nullptr && which == 0 && S->x_pending;
+  const bool owed    = useX && S->x_pending;
   const double alpha = S->alpha;
   if (stopped) return;
-  for (; i < n2; i += stride) {
-    double2 o;
+  auto finish = [&](uint32_t j, const double2& a, const double2& b, double2 xv) {
     if (owed) {
       xv.x = xv.x + alpha * b.x;
       xv.y = xv.y + alpha * b.y;
-      x2[i] = xv;
+      x2[j] = xv;
     }
+    double2 o;
     o.x = a.x + beta * b.x;
     o.y = a.y + beta * b.y;
-    p2[i] = o;
-    const uint32_t nx = i + stride;
-    if (nx < n2) {
-      a = r2[nx];
-      b = which == 0 ? p2[nx] : a;
-      if (owed) xv = x2[nx];
-    }
+    p2[j] = o;
+  };
+  for (; i < n2; i += 2u * stride) {
+    const bool second = i + stride < n2;
+    finish(i, a0, b0, x0);
+    if (second) finish(i + stride, a1, b1, x1);
+    const uint32_t nx = i + 2u * stride;
+    if (nx < n2) load(nx, a0, b0, x0), load(min(nx + stride, last), a1, b1, x1);
   }
   if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) {
     const double bb = which == 0 ? p[n - 1] : r[n - 1];
