@@ -633,12 +633,10 @@ __global__ __launch_bounds__(64) void p2p_selftest_k(const P2PView* pv, unsigned
 }
 
 // CG scalar step as its own launch: the reference-shaped (unfused) path, and after the
-// all-reduce on several ranks (REDUCE = false: the sum is already in S->local).  With pv != NULL
-// the all-reduce happens right here (p2p_allreduce_sum) and the step follows in the same launch.
-template <int MODE, bool REDUCE, bool P2P = false>
+// all-reduce on several ranks (REDUCE = false: the sum is already in S->local).
+template <int MODE, bool REDUCE>
 __global__ __launch_bounds__(1024) void cg_scalar_k(uint32_t m, const double* __restrict__ q,
-    CgScalars* S, double* __restrict__ rr_hist, double* __restrict__ pAp_hist, int to_local, int defer_x,
-    const P2PView* pv, unsigned long long seq)
+    CgScalars* S, double* __restrict__ rr_hist, double* __restrict__ pAp_hist, int to_local, int defer_x)
 {
   __shared__ double lds16[16];
   // This launch sits on the critical path of every iteration: do not serialise the flag's
@@ -653,19 +651,31 @@ __global__ __launch_bounds__(1024) void cg_scalar_k(uint32_t m, const double* __
       if (threadIdx.x == 0) S->local = total;
       return;
     }
-    if (P2P) { // (its own instantiation: the single-rank step stays as small as it was)
-      __syncthreads(); // lds16 is reused
-      total = p2p_allreduce_sum(pv, total, seq, lds16, &S->p2p_error);
-      if (S->p2p_error) { // uniform: written before the barriers inside
-        if (threadIdx.x == 0) S->stop = 1;
-        return;
-      }
-    }
   } else {
     total = S->local;
     if (stopped) return;
   }
   __syncthreads();
+  if (threadIdx.x == 0) cg_apply<MODE>(S, total, rr_hist, pAp_hist, defer_x);
+}
+
+// The same step on several ranks with the all-reduce inside (p2p_allreduce_sum): local levels
+// 1-2, exchange, step -- one launch.  (Its own kernel: the single-rank step above stays as it is.)
+template <int MODE>
+__global__ __launch_bounds__(1024) void cg_scalar_p2p_k(uint32_t m, const double* __restrict__ q,
+    CgScalars* S, double* __restrict__ rr_hist, double* __restrict__ pAp_hist, int defer_x,
+    const P2PView* __restrict__ pv, unsigned long long seq)
+{
+  __shared__ double lds16[16];
+  const int stopped = S->stop; // identical on every rank: all of them skip the exchange, or none
+  double total      = reduce_final_1024(m, q, lds16);
+  if (stopped) return;
+  __syncthreads(); // lds16 is reused
+  total = p2p_allreduce_sum(pv, total, seq, lds16, &S->p2p_error);
+  if (S->p2p_error) { // uniform: raised before the barriers inside the exchange
+    if (threadIdx.x == 0) S->stop = 1;
+    return;
+  }
   if (threadIdx.x == 0) cg_apply<MODE>(S, total, rr_hist, pAp_hist, defer_x);
 }
 

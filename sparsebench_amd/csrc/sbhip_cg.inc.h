@@ -133,20 +133,20 @@ static bool spmv_can_fuse_dot(const sb_cg* s)
 template <int MODE> static void scalar_launch(sb_cg* s, int defer_x = 0)
 {
   if (multi_rank() && g.p2pOn) { // local reduce, in-kernel all-reduce and scalar step in ONE launch
-    hipLaunchKernelGGL((cg_scalar_k<MODE, true, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
-        s->S, s->rr_hist, s->pAp_hist, 0, defer_x, (const P2PView*)g.p2pView, ++g.p2pSeq);
+    hipLaunchKernelGGL((cg_scalar_p2p_k<MODE>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
+        s->S, s->rr_hist, s->pAp_hist, defer_x, (const P2PView*)g.p2pView, ++g.p2pSeq);
     HIP_CHECK(hipGetLastError());
     return;
   }
   hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
-      s->S, s->rr_hist, s->pAp_hist, multi_rank() ? 1 : 0, defer_x, (const P2PView*)nullptr, 0ull);
+      s->S, s->rr_hist, s->pAp_hist, multi_rank() ? 1 : 0, defer_x);
   HIP_CHECK(hipGetLastError());
   if (multi_rank()) {
     mark(s, R_DDOT);
     sb_comm_reduction(&s->S->local, 1);
     mark(s, R_COMM);
     hipLaunchKernelGGL((cg_scalar_k<MODE, false>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, s->partials,
-        s->S, s->rr_hist, s->pAp_hist, 0, defer_x, (const P2PView*)nullptr, 0ull);
+        s->S, s->rr_hist, s->pAp_hist, 0, defer_x);
     HIP_CHECK(hipGetLastError());
   }
 }
