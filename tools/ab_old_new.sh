@@ -1,3 +1,12 @@
+#!/usr/bin/env bash
+# Same-box A/B of two builds of libsbhip.so inside CG (rocprofv3 kernel averages): the product library
+# against labs/old/libsbhip.so, e.g. built from an earlier commit:
+#   git archive <commit> | tar -x -C /tmp/oldsrc
+#   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -shared \
+#         -o labs/old/libsbhip.so /tmp/oldsrc/sparsebench_amd/csrc/sbhip.hip -ldl
+# (an older library must export every symbol sparsebench_amd/capi.py lists; add stubs if needed).
+# LD_PRELOAD makes the host library bind to the same old build that SBHIP_LIBRARY hands to ctypes.
+# Run on the GPU box:  gpurun -- bash tools/ab_old_new.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for v in new old new old; do
   if [ $v = old ]; then export LD_PRELOAD=$PWD/labs/old/libsbhip.so SBHIP_LIBRARY=$PWD/labs/old/libsbhip.so; else unset LD_PRELOAD SBHIP_LIBRARY; fi
