@@ -288,6 +288,8 @@ def main():
                        "parallelism": "1d_block_row_x%d" % world,
                        "transport": ("none" if world == 1 else "rccl_xgmi" if args.transport == "rccl"
                                      else "host_staged_gloo (rehearsal)"),
+                       "dot_allreduce": ("none" if world == 1 else "in_kernel_peer_mapped" if L.sb_comm_p2p_enabled()
+                                         else "rccl" if args.transport == "rccl" else "host_staged_gloo"),
                        "fused_dots": True,
                        "hip_graph": bool(args.graph)},
             "global_iterations_per_s": it_s,
