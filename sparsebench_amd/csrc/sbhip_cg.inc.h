@@ -202,7 +202,10 @@ static void loop_body(sb_cg* s, int k)
     mark(s, R_WAXPBY);
   }
   HIP_CHECK(hipGetLastError());
-  static const bool overlapHalo = !(getenv("SB_HALO_OVERLAP") && atoi(getenv("SB_HALO_OVERLAP")) == 0);
+  // Off by default: a cross-stream event dependency costs ~12 us on this platform (measured with
+  // an x update moved beside the beta step: 63 -> 88 us per iteration for one fork + join), which
+  // is about what the overlap can hide.  SB_HALO_OVERLAP=1 enables it.
+  static const bool overlapHalo = getenv("SB_HALO_OVERLAP") && atoi(getenv("SB_HALO_OVERLAP")) != 0;
   if (overlapHalo && multi_rank() && s->halo && spmv_can_fuse_dot(s) && spmv_can_split(s->A)) {
     // :122-126 with the halo exchange hidden behind the interior tiles: the exchange (pack,
     // send/recv into the tail of p) AND the few halo-touching tiles that need it run on a
