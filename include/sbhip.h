@@ -146,6 +146,9 @@ typedef struct {
   void (*neighbour_exchange)(void* ctx, const double* send_dev, int outdegree, const int* destinations,
                              const int* sendCounts, const int* sdispls, double* recv_dev, int indegree,
                              const int* sources, const int* recvCounts, const int* rdispls);
+  /* optional (may be NULL): all_host[r * nbytes ..] = rank r's mine_host; lets the layer set up the
+   * exchange over peer-mapped memory (halo staging areas) on top of this transport */
+  void (*allgather_bytes)(void* ctx, const void* mine_host, int nbytes, void* all_host);
 } sb_transport;
 void sb_comm_init_transport(int rank, int size, const sb_transport* t);
 /* In-kernel all-reduce of the CG scalars over peer-mapped memory (one launch per dot instead of

@@ -140,8 +140,12 @@ EXCHANGE_FN = C.CFUNCTYPE(None, vp, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C
                           vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 
 
+ALLGATHER_BYTES_FN = C.CFUNCTYPE(None, vp, vp, C.c_int, vp)
+
+
 class TransportS(C.Structure):
-    _fields_ = [("ctx", vp), ("allreduce", ALLREDUCE_FN), ("neighbour_exchange", EXCHANGE_FN)]
+    _fields_ = [("ctx", vp), ("allreduce", ALLREDUCE_FN), ("neighbour_exchange", EXCHANGE_FN),
+                ("allgather_bytes", ALLGATHER_BYTES_FN)]
 
 
 def init(device=None):

@@ -632,6 +632,84 @@ __global__ __launch_bounds__(64) void p2p_selftest_k(const P2PView* pv, unsigned
   if (threadIdx.x == 0) *out = r;
 }
 
+// =============================================================================
+// Halo exchange over peer-mapped memory (same ingredients as p2p_allreduce_sum).  Every rank
+// owns a fine-grained staging area [2][externalCount] + flags [2][P2P_MAX] that its neighbours
+// have mapped (HIP IPC).  halo_push_k packs x[elementsToSend] (src/comm.c:635-638) and stores
+// every value straight into the slot the receiver expects it in (its rdispl + offset); the
+// last workgroup to finish raises the sequence flag at every destination (system-scope
+// release).  halo_pull_k (one workgroup per source) waits for its source's flag (bounded) and
+// copies the block into the tail of x (src/comm.c:640-648 receives there).  Two launches, no
+// RCCL call in the loop.  Parity-alternating areas: between two exchanges lie two all-reduces,
+// so no rank is more than one exchange ahead of a neighbour.
+// =============================================================================
+struct HaloPush {
+  uint32_t n;               // elements to send
+  int ndest, rank;
+  const uint32_t* packIdx;  // row (in the vector's order) of each element
+  const uint32_t* slot;     // its position in the receiver's staging area
+  const uint8_t* dest;      // which destination (index into the arrays below)
+  unsigned int* done;       // workgroups finished (last-block protocol)
+  unsigned long long* stage[P2P_MAX]; // destination i's staging area, as mapped here
+  unsigned long long* flag[P2P_MAX];  // destination i's flags
+  uint32_t ext[P2P_MAX];              // destination i's externalCount (area stride)
+};
+
+__global__ __launch_bounds__(256) void halo_push_k(HaloPush hp, const double* __restrict__ x,
+    unsigned long long seq, const int* __restrict__ stop)
+{
+  if (stop && *stop) return; // the same decision on every rank (the loop test is all-reduced)
+  const unsigned par    = (unsigned)(seq & 1ull);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < hp.n; i += stride) {
+    const uint32_t d = hp.dest[i];
+    __hip_atomic_store(hp.stage[d] + (size_t)par * hp.ext[d] + hp.slot[i],
+        (unsigned long long)__double_as_longlong(x[hp.packIdx[i]]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system(); // this thread's stores are out before its workgroup counts itself done
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = atomicAdd(hp.done, 1u);
+    if (prev == gridDim.x - 1u) { // every workgroup has pushed: tell the receivers
+      *hp.done = 0u;
+      __threadfence_system();
+      for (int d = 0; d < hp.ndest; d++)
+        __hip_atomic_store(hp.flag[d] + par * P2P_MAX + hp.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void halo_pull_k(const int* __restrict__ srcRank, const int* __restrict__ rdispl,
+    const int* __restrict__ rcount, const unsigned long long* stage, const unsigned long long* flags,
+    uint32_t ext, double* __restrict__ xTail, unsigned long long seq, int* err, const int* __restrict__ stop)
+{
+  __shared__ int ok;
+  if (stop && *stop) return;
+  const unsigned par = (unsigned)(seq & 1ull);
+  const int j        = (int)blockIdx.x;
+  if (threadIdx.x == 0) {
+    const unsigned long long* f = flags + par * P2P_MAX + srcRank[j];
+    const long long t0          = wall_clock64();
+    int good                    = 1;
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) {
+        good = 0;
+        atomicExch(err, 1);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    ok = good;
+  }
+  __syncthreads();
+  if (!ok) return;
+  // plain loads: thread 0's system-scope acquire + the barrier order them after the sender's
+  // stores (one atomic load per element would serialise into one ~2 us round trip each)
+  const double* src = reinterpret_cast<const double*>(stage + (size_t)par * ext + rdispl[j]);
+  double* dst       = xTail + rdispl[j];
+  for (int i = (int)threadIdx.x; i < rcount[j]; i += 256) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
 // CG scalar step as its own launch: the reference-shaped (unfused) path, and after the
 // all-reduce on several ranks (REDUCE = false: the sum is already in S->local).
 template <int MODE, bool REDUCE>

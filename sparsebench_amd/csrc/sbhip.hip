@@ -217,6 +217,14 @@ struct sb_halo {
   std::vector<int> destinations, sendCounts, sdispls, sources, recvCounts, rdispls;
   uint32_t* packIdx = nullptr; // device: row (in the vector's order) of each sent element
   double* sendBuf = nullptr;   // device
+  // exchange over peer-mapped memory (kernels.hip.h: halo_push_k / halo_pull_k); p2p == false: RCCL / transport
+  bool p2p = false;
+  unsigned long long* stage = nullptr; // own fine-grained area: [2][externalCount] values, then [2][P2P_MAX] flags
+  void* peerStage[P2P_MAX] = {};       // destinations' areas as opened here (by destination index)
+  HaloPush push;                       // kernel argument of halo_push_k
+  uint32_t *slot = nullptr; uint8_t* dest = nullptr; unsigned int* done = nullptr; // device arrays behind `push`
+  int *dSrcRank = nullptr, *dRdispl = nullptr, *dRcount = nullptr, *err = nullptr;
+  unsigned long long seq = 0;
 };
 
 struct sb_cg {

@@ -218,7 +218,7 @@ static void loop_body(sb_cg* s, int k)
     //  there, but the fork / join is the same code)
     HIP_CHECK(hipEventRecord(g.evFork, g.stream));
     HIP_CHECK(hipStreamWaitEvent(g.stream2, g.evFork, 0));
-    halo_exchange(s->halo, s->p, stop, g.stream2);
+    halo_exchange(s->halo, s->p, stop, g.stream2, true);
     launch_spmv(s->A, s->p, s->Ap, s->partials, stop, 2, g.stream2);
     HIP_CHECK(hipEventRecord(g.evJoin, g.stream2));
     launch_spmv(s->A, s->p, s->Ap, s->partials, stop, 1);
@@ -226,7 +226,7 @@ static void loop_body(sb_cg* s, int k)
     spmv_event(s);
     mark(s, R_SPMVM);
   } else {
-    halo_exchange(s->halo, s->p, stop); // :122
+    halo_exchange(s->halo, s->p, stop, nullptr, true); // :122
     mark(s, R_COMM);
     spmv_event(s);
     spmv_and_pAp(s, stop);
@@ -331,6 +331,11 @@ int sb_cg_finish(sb_cg* s)
   if (h.p2p_error)
     SB_FATAL("rank %d: a peer's contribution to an in-kernel all-reduce did not arrive within 2 s "
              "(SB_P2P=0 selects the RCCL all-reduce)", g.rank);
+  if (s->halo && s->halo->p2p) {
+    int e = 0;
+    HIP_CHECK(hipMemcpy(&e, s->halo->err, sizeof e, hipMemcpyDeviceToHost));
+    if (e) SB_FATAL("rank %d: a neighbour's halo block did not arrive within 2 s (SB_P2P_HALO=0 selects RCCL)", g.rank);
+  }
   if (s->timing) {
     for (double& v : s->region_ms) v = 0.0;
     for (size_t i = 1; i < s->evUsed; i++) {

@@ -244,6 +244,141 @@ void sb_comm_barrier(void)
   HIP_CHECK(hipStreamSynchronize(g.stream));
 }
 
+// ---- halo exchange over peer-mapped memory: collective set-up (every rank calls sb_halo_create) -------
+static void halo_exchange(sb_halo* h, double* x, const int* stop, hipStream_t stream = nullptr, bool inCG = false);
+
+static void halo_p2p_release(sb_halo* h)
+{
+  for (int i = 0; i < P2P_MAX; i++) {
+    if (h->peerStage[i]) (void)hipIpcCloseMemHandle(h->peerStage[i]);
+    h->peerStage[i] = nullptr;
+  }
+  if (h->stage) (void)hipFree(h->stage);
+  sb_free(h->slot), sb_free(h->dest), sb_free(h->done), sb_free(h->dSrcRank), sb_free(h->dRdispl), sb_free(h->dRcount);
+  sb_free(h->err);
+  h->stage = nullptr, h->slot = nullptr, h->dest = nullptr, h->done = nullptr, h->dSrcRank = nullptr;
+  h->dRdispl = nullptr, h->dRcount = nullptr, h->err = nullptr, h->p2p = false;
+}
+
+static bool comm_can_allgather() { return g.comm != nullptr || (g.hasXport && g.xport.allgather_bytes != nullptr); }
+static void comm_allgather(const void* mine, int nbytes, void* all)
+{
+  if (g.comm) sb_comm_allgather_bytes(mine, nbytes, all);
+  else g.xport.allgather_bytes(g.xport.ctx, mine, nbytes, all);
+}
+
+static void halo_p2p_setup(sb_halo* h)
+{
+  const char* env = getenv("SB_P2P_HALO");
+  // rides on the in-kernel all-reduce's decision (same memory model, same agreement); needs an
+  // all-gather for the handles.  Every condition here is the same on every rank.
+  if (!g.p2pOn || g.size > P2P_MAX || !comm_can_allgather() || (env && atoi(env) == 0)) return;
+  const int P = g.size, E = h->externalCount;
+  int ok      = 1;
+  // 1. own staging area + flags, exported
+  struct Info {
+    unsigned char handle[SB_P2P_HANDLE_BYTES];
+    int ext;
+    int rdisplOf[P2P_MAX]; // where rank r's block starts in my area, -1: r sends me nothing
+  } mine, all[P2P_MAX];
+  memset(&mine, 0, sizeof mine);
+  mine.ext = E;
+  for (int r = 0; r < P2P_MAX; r++) mine.rdisplOf[r] = -1;
+  for (int j = 0; j < h->indegree; j++) mine.rdisplOf[h->sources[j]] = h->rdispls[j];
+  const size_t words = 2 * (size_t)E + 2 * P2P_MAX + 8;
+  void* buf          = nullptr;
+  if (hipExtMallocWithFlags(&buf, words * sizeof(unsigned long long), hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    ok = 0;
+  } else {
+    h->stage = (unsigned long long*)buf;
+    HIP_CHECK(hipMemset(h->stage, 0, words * sizeof(unsigned long long)));
+    HIP_CHECK(hipDeviceSynchronize());
+    hipIpcMemHandle_t ih;
+    if (hipIpcGetMemHandle(&ih, h->stage) != hipSuccess) {
+      (void)hipGetLastError();
+      ok = 0;
+    } else memcpy(mine.handle, &ih, sizeof ih);
+  }
+  comm_allgather(&mine, (int)sizeof mine, all);
+  // 2. map the destinations, work out where every sent element lands
+  memset(&h->push, 0, sizeof h->push);
+  std::vector<uint32_t> slot((size_t)h->totalSend);
+  std::vector<uint8_t> dest((size_t)h->totalSend);
+  unsigned char zero[SB_P2P_HANDLE_BYTES] = { 0 };
+  for (int i = 0; ok && i < h->outdegree; i++) {
+    const int d = h->destinations[i];
+    if (i >= P2P_MAX || memcmp(all[d].handle, zero, sizeof zero) == 0 || all[d].rdisplOf[g.rank] < 0) {
+      ok = 0;
+      break;
+    }
+    hipIpcMemHandle_t ih;
+    memcpy(&ih, all[d].handle, sizeof ih);
+    if (hipIpcOpenMemHandle(&h->peerStage[i], ih, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+      (void)hipGetLastError();
+      h->peerStage[i] = nullptr;
+      ok = 0;
+      break;
+    }
+    h->push.stage[i] = (unsigned long long*)h->peerStage[i];
+    h->push.flag[i]  = (unsigned long long*)h->peerStage[i] + 2 * (size_t)all[d].ext;
+    h->push.ext[i]   = (uint32_t)all[d].ext;
+    for (int e = 0; e < h->sendCounts[i]; e++) {
+      slot[(size_t)h->sdispls[i] + e] = (uint32_t)(all[d].rdisplOf[g.rank] + e);
+      dest[(size_t)h->sdispls[i] + e] = (uint8_t)i;
+    }
+  }
+  // 3. every rank must come to the same decision, before and after one tested exchange
+  double* dflag = (double*)sb_malloc(sizeof(double));
+  auto agree = [&](int good) {
+    const double v = good ? 1.0 : 0.0;
+    sb_h2d(dflag, &v, sizeof v);
+    sb_comm_reduction(dflag, 1);
+    double sum = 0.0;
+    sb_d2h(&sum, dflag, sizeof sum);
+    return sum == (double)P;
+  };
+  bool on = agree(ok);
+  if (on) {
+    h->slot = (uint32_t*)upload(slot.data(), slot.size() * sizeof(uint32_t));
+    h->dest = (uint8_t*)upload(dest.data(), dest.size());
+    h->done = (unsigned int*)sb_malloc(sizeof(unsigned int));
+    h->err  = (int*)sb_malloc(sizeof(int));
+    HIP_CHECK(hipMemset(h->done, 0, sizeof(unsigned int)));
+    HIP_CHECK(hipMemset(h->err, 0, sizeof(int)));
+    h->dSrcRank = (int*)upload(h->sources.data(), h->sources.size() * sizeof(int));
+    h->dRdispl  = (int*)upload(h->rdispls.data(), h->rdispls.size() * sizeof(int));
+    h->dRcount  = (int*)upload(h->recvCounts.data(), h->recvCounts.size() * sizeof(int));
+    h->push.n = (uint32_t)h->totalSend, h->push.ndest = h->outdegree, h->push.rank = g.rank;
+    h->push.packIdx = h->packIdx, h->push.slot = h->slot, h->push.dest = h->dest, h->push.done = h->done;
+    // self-test: every rank sends (rank + 1) in all its slots; the block from source s must read s + 1
+    const size_t nvec = (size_t)h->nr + (size_t)E + 1;
+    double* v         = (double*)sb_malloc(nvec * sizeof(double));
+    std::vector<double> host(nvec, (double)(g.rank + 1));
+    sb_h2d(v, host.data(), nvec * sizeof(double));
+    h->p2p = true;
+    halo_exchange(h, v, nullptr, g.stream, true);
+    sb_d2h(host.data(), v, nvec * sizeof(double));
+    int e = 0;
+    sb_d2h(&e, h->err, sizeof e);
+    int good = !e;
+    for (int j = 0; good && j < h->indegree; j++)
+      for (int i = 0; i < h->recvCounts[j]; i++)
+        if (host[(size_t)h->nr + h->rdispls[j] + i] != (double)(h->sources[j] + 1)) {
+          good = 0;
+          break;
+        }
+    sb_free(v);
+    on = agree(good);
+  }
+  sb_free(dflag);
+  if (!on) halo_p2p_release(h);
+  h->p2p = on;
+  if (getenv("SB_PACK_REPORT") || getenv("SB_P2P_REPORT"))
+    fprintf(stderr, "sbhip comm: rank %d/%d halo exchange over peer-mapped memory: %s\n", g.rank, g.size,
+        on ? "on" : "off (RCCL / transport send-recv)");
+}
+
 sb_halo* sb_halo_create(uint32_t nr, int outdegree, const int* destinations, const int* sendCounts,
     const int* sdispls, int indegree, const int* sources, const int* recvCounts, const int* rdispls,
     const int* elementsToSend, int totalSendCount, int externalCount, const uint32_t* oldToNewPerm)
@@ -281,6 +416,7 @@ sb_halo* sb_halo_create(uint32_t nr, int outdegree, const int* destinations, con
   }
   h->packIdx = (uint32_t*)upload(idx.data(), idx.size() * sizeof(uint32_t));
   HIP_CHECK(hipMalloc(&h->sendBuf, ((size_t)totalSendCount + 1) * sizeof(double)));
+  halo_p2p_setup(h);
   return h;
 }
 
@@ -288,13 +424,26 @@ void sb_halo_free(sb_halo* h)
 {
   if (!h) return;
   sb_free(h->packIdx), sb_free(h->sendBuf);
+  halo_p2p_release(h);
   delete h;
 }
 
-static void halo_exchange(sb_halo* h, double* x, const int* stop, hipStream_t stream = nullptr)
+// inCG: the caller guarantees an all-reduce between any two exchanges (the CG loop: two per
+// iteration), which is what lets the peer-mapped path alternate between just two staging areas.
+static void halo_exchange(sb_halo* h, double* x, const int* stop, hipStream_t stream, bool inCG)
 {
   if (!h || g.size == 1) return;
   if (!stream) stream = g.stream;
+  if (h->p2p && inCG) { // push into the neighbours' staging areas, pull the own one into the tail of x
+    const unsigned long long seq = ++h->seq;
+    if (h->totalSend)
+      hipLaunchKernelGGL(halo_push_k, dim3(stream_grid(h->totalSend, 256)), dim3(256), 0, stream, h->push, x, seq, stop);
+    if (h->indegree)
+      hipLaunchKernelGGL(halo_pull_k, dim3(h->indegree), dim3(256), 0, stream, h->dSrcRank, h->dRdispl, h->dRcount,
+          h->stage, h->stage + 2 * (size_t)h->externalCount, (uint32_t)h->externalCount, x + h->nr, seq, h->err, stop);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (h->totalSend) {
     hipLaunchKernelGGL(gather_k, dim3(stream_grid(h->totalSend, 256)), dim3(256), 0, stream,
         (uint32_t)h->totalSend, h->packIdx, x, h->sendBuf, stop);

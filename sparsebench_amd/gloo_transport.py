@@ -87,8 +87,14 @@ def attach(L, H, dist, rank, size):
     cb1, cb2 = hostapi.ALLGATHER_FN(allgather), hostapi.ALLTOALLV_FN(alltoallv)
     xchg = hostapi.ExchangeS(None, cb1, cb2)
     H.commSetExchange(C.byref(xchg))
-    cb3, cb4 = capi.ALLREDUCE_FN(allreduce), capi.EXCHANGE_FN(exchange)
-    tr = capi.TransportS(None, cb3, cb4)
+    def allgather_bytes(ctx, mine, nbytes, out):
+        t = torch.tensor(list(C.string_at(mine, nbytes)), dtype=torch.uint8)
+        outs = [torch.zeros(nbytes, dtype=torch.uint8) for _ in range(size)]
+        dist.all_gather(outs, t)
+        C.memmove(out, bytes(torch.cat(outs).tolist()), nbytes * size)
+
+    cb3, cb4, cb5 = capi.ALLREDUCE_FN(allreduce), capi.EXCHANGE_FN(exchange), capi.ALLGATHER_BYTES_FN(allgather_bytes)
+    tr = capi.TransportS(None, cb3, cb4, cb5)
     L.sb_comm_init_transport(rank, size, C.byref(tr))
     # in-kernel all-reduce over peer-mapped memory (include/sbhip.h): gather the IPC handles, open, self-test
     mine = (C.c_ubyte * 64)()
@@ -98,4 +104,4 @@ def attach(L, H, dist, rank, size):
     dist.all_gather(outs, t)
     allh = (C.c_ubyte * (64 * size))(*torch.cat(outs).tolist())
     L.sb_comm_p2p_open(allh if have else None)
-    return (cb1, cb2, xchg, cb3, cb4, tr)
+    return (cb1, cb2, xchg, cb3, cb4, cb5, tr)
