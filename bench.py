@@ -288,6 +288,8 @@ def main():
                        "parallelism": "1d_block_row_x%d" % world,
                        "transport": ("none" if world == 1 else "rccl_xgmi" if args.transport == "rccl"
                                      else "host_staged_gloo (rehearsal)"),
+                       "halo_exchange": ("none" if world == 1 else "peer_mapped_push_pull" if L.sb_halo_p2p_enabled(prob.halo)
+                                         else "rccl_send_recv" if args.transport == "rccl" else "host_staged_gloo"),
                        "dot_allreduce": ("none" if world == 1 else "in_kernel_peer_mapped" if L.sb_comm_p2p_enabled()
                                          else "rccl" if args.transport == "rccl" else "host_staged_gloo"),
                        "fused_dots": True,

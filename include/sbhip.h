@@ -183,6 +183,10 @@ sb_halo* sb_halo_create(uint32_t nr, int outdegree, const int* destinations,
                         const int* elementsToSend, int totalSendCount, int externalCount,
                         const uint32_t* oldToNewPerm);
 void sb_halo_free(sb_halo* h);
+/* 1: inside CG this halo is exchanged by push / pull kernels over peer-mapped staging areas (set up
+ * collectively in sb_halo_create when the in-kernel all-reduce is on; SB_P2P_HALO=0 disables), 0: RCCL /
+ * transport send-recv */
+int sb_halo_p2p_enabled(const sb_halo* h);
 /* commExchange, src/comm.h:57: pack x[elementsToSend] and deliver every
  * neighbour's slice into x[numRows ...]; stream-ordered */
 void sb_halo_exchange(sb_halo* h, double* x);

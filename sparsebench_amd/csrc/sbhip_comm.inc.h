@@ -420,6 +420,8 @@ sb_halo* sb_halo_create(uint32_t nr, int outdegree, const int* destinations, con
   return h;
 }
 
+int sb_halo_p2p_enabled(const sb_halo* h) { return h && h->p2p ? 1 : 0; }
+
 void sb_halo_free(sb_halo* h)
 {
   if (!h) return;
