@@ -506,6 +506,22 @@ constexpr int PAT_STOP_LANE          = 48; // the lane that fetches the stop fla
 // <= 6 segments, listed longest first: three of <= 768 entries (3 loads per thread) and three
 // of <= 256 (1 load): staged segment by segment, no per-entry search
 constexpr uint32_t PAT_SIMPLE_WINDOW = 1u;
+constexpr uint32_t PAT_TOUCHES_HALO  = 2u; // the window holds columns >= nr (entries of other ranks)
+
+// HALO instantiation of spmv_scs64_pat (several ranks, peer-mapped halo exchange, kernels.hip.h):
+// the neighbours' halo_push_k kernels store straight into this rank's staging area; instead of a
+// separate pull launch, the few tiles that touch halo columns wait for the sources' sequence flags
+// themselves and read those columns from the staging area.  They are stored last (interior tiles
+// first), so by the time they run the data is normally there: the exchange hides behind the
+// interior tiles inside ONE kernel, without a second stream.
+struct HaloWait {
+  const unsigned long long* flags; // own flags, [2][P2P_MAX]
+  const double* ext;               // own staging area of this exchange's parity: column c >= nr is ext[c - nr]
+  const int* src;                  // source ranks
+  int nsrc;
+  unsigned long long seq;
+  int* err;
+};
 constexpr uint32_t PAT_EXC_LDS_MAX   = 1024; // exception entries per tile (16 KiB of LDS) at most
 
 // dominant code sequence of every chunk (majority of the 64 lanes) and the lanes that differ
@@ -580,14 +596,14 @@ __global__ __launch_bounds__(256) void pat_compact_k(const PackMeta* __restrict_
 // SKIPPAD: padded elements are NOT added (the reference's Sell-C-sigma loop adds 0.0 * x[0]
 // for them, src/matrix-SCS.c:151-155 / :208-227; its CRS loop has no such elements,
 // src/matrix-CRS.c:46-65) -- the instantiation behind the CRS format's private mirror.
-template <bool DOT, bool SKIPPAD>
+template <bool DOT, bool SKIPPAD, bool HALO>
 __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict__ hdrs,
     const uint32_t* __restrict__ stream, const uint16_t* __restrict__ rowBase,
     const PatEntry* __restrict__ classDict, const PatEntry* __restrict__ rowPats,
     const PatEntry* __restrict__ excRows, const TileSeg* __restrict__ segs,
     const double* __restrict__ x, double* __restrict__ y, uint32_t nr, uint32_t nChunks,
     uint32_t firstHdr, uint32_t nHdrs, uint32_t blocksPerXcd, uint32_t padCol, uint32_t dictEntries,
-    uint32_t excLds, double* __restrict__ dotPartials, const int* __restrict__ stop)
+    uint32_t excLds, double* __restrict__ dotPartials, const int* __restrict__ stop, HaloWait hw)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[]; // [dict][exception entries + 8][window]
   PatEntry* sd = reinterpret_cast<PatEntry*>(lds);
@@ -621,6 +637,24 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   const uint32_t cls = field(0), nseg = field(1), winInline = field(30), flags = field(31);
   const uint32_t excStart = field(44), excCount = field(45);
   const bool simple = (flags & PAT_SIMPLE_WINDOW) != 0u; // uniform per workgroup
+  if (HALO && (flags & PAT_TOUCHES_HALO) && !stopped && tile0 < nHdrs) { // wait for the neighbours' blocks
+    if ((int)threadIdx.x < hw.nsrc) {
+      const unsigned long long* f = hw.flags + (hw.seq & 1ull) * P2P_MAX + hw.src[threadIdx.x];
+      const long long t0          = wall_clock64();
+      while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != hw.seq) {
+        if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) {
+          atomicExch(hw.err, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __syncthreads();
+  }
+  auto xcol = [&](uint32_t col) -> double { // x by column; halo columns come from the staging area
+    if (HALO) return *(col >= nr ? hw.ext + (col - nr) : x + col);
+    return x[col];
+  };
   // round trip 2: codes (L chunks), row bases, own x entries, tables, x window -- addresses
   // clamped into valid memory so that nothing waits for a branch
   const bool isExc      = uni && ((lane < 32u ? excLo >> lane : excHi >> (lane - 32u)) & 1u) != 0u;
@@ -647,12 +681,12 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
     for (int sI = 0; sI < 3; sI++) {
       const uint32_t sc = field(12 + 3 * sI), sn = field(12 + 3 * sI + 2);
 #pragma unroll
-      for (int r = 0; r < 3; r++) t[sI * 3 + r] = x[sn ? sc + min((uint32_t)r * 256u + threadIdx.x, sn - 1u) : padCol];
+      for (int r = 0; r < 3; r++) t[sI * 3 + r] = xcol(sn ? sc + min((uint32_t)r * 256u + threadIdx.x, sn - 1u) : padCol);
     }
 #pragma unroll
     for (int sI = 3; sI < 6; sI++) {
       const uint32_t sc = field(12 + 3 * sI), sn = field(12 + 3 * sI + 2);
-      t[6 + sI] = x[sn ? sc + min(threadIdx.x, sn - 1u) : padCol];
+      t[6 + sI] = xcol(sn ? sc + min(threadIdx.x, sn - 1u) : padCol);
     }
   } else { // slot by slot over the inline segments
     uint32_t segCol[PAT_INLINE_SEGS], segFirst[PAT_INLINE_SEGS];
@@ -664,7 +698,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
       uint32_t col        = padCol;
 #pragma unroll
       for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++) col = slot >= segFirst[s] ? segCol[s] + (slot - segFirst[s]) : col;
-      t[k] = x[col];
+      t[k] = xcol(col);
     }
   }
   // keep every load above in front of the exit test (the compiler would sink them behind it)
@@ -704,12 +738,12 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
       uint32_t col        = padCol;
 #pragma unroll
       for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++) col = slot >= segFirst[s] ? segCol[s] + (slot - segFirst[s]) : col;
-      if (slot < winInline) sx[slot] = x[col];
+      if (slot < winInline) sx[slot] = xcol(col);
     }
     const uint32_t segPtr = field(2);
     for (uint32_t s = PAT_INLINE_SEGS; s < nseg; s++) { // rare: tiles with many ranges
       const TileSeg sg = segs[segPtr + s];
-      for (uint32_t i = threadIdx.x; i < sg.len; i += 256u) sx[sg.lds + i] = x[sg.col + i];
+      for (uint32_t i = threadIdx.x; i < sg.len; i += 256u) sx[sg.lds + i] = xcol(sg.col + i);
     }
   }
   // offsets become LDS byte addresses here (once per staged entry, not once per use)

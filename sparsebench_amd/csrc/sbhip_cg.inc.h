@@ -225,6 +225,20 @@ static void loop_body(sb_cg* s, int k)
     HIP_CHECK(hipStreamWaitEvent(g.stream, g.evJoin, 0));
     spmv_event(s);
     mark(s, R_SPMVM);
+  } else if (multi_rank() && s->halo && s->halo->p2p && spmv_can_fuse_dot(s) && spmv_uses_patterns(s->A)) {
+    // :122-126 over peer-mapped memory with the pull inside the SpMV: the halo-touching tiles (stored
+    // last) wait for the neighbours' pushes themselves and read the staging area; interior tiles hide it
+    halo_exchange(s->halo, s->p, stop, nullptr, true, true);
+    mark(s, R_COMM);
+    sb_halo* h = s->halo;
+    HaloWait hw;
+    hw.flags = h->stage + 2 * (size_t)h->externalCount;
+    hw.ext   = reinterpret_cast<const double*>(h->stage + (h->seq & 1ull) * (size_t)h->externalCount);
+    hw.src = h->dSrcRank, hw.nsrc = h->indegree, hw.seq = h->seq, hw.err = h->err;
+    spmv_event(s);
+    launch_spmv(s->A, s->p, s->Ap, s->partials, stop, 0, nullptr, &hw);
+    spmv_event(s);
+    mark(s, R_SPMVM);
   } else {
     halo_exchange(s->halo, s->p, stop, nullptr, true); // :122
     mark(s, R_COMM);

@@ -245,7 +245,8 @@ void sb_comm_barrier(void)
 }
 
 // ---- halo exchange over peer-mapped memory: collective set-up (every rank calls sb_halo_create) -------
-static void halo_exchange(sb_halo* h, double* x, const int* stop, hipStream_t stream = nullptr, bool inCG = false);
+static void halo_exchange(sb_halo* h, double* x, const int* stop, hipStream_t stream = nullptr, bool inCG = false,
+    bool pushOnly = false);
 
 static void halo_p2p_release(sb_halo* h)
 {
@@ -432,7 +433,8 @@ void sb_halo_free(sb_halo* h)
 
 // inCG: the caller guarantees an all-reduce between any two exchanges (the CG loop: two per
 // iteration), which is what lets the peer-mapped path alternate between just two staging areas.
-static void halo_exchange(sb_halo* h, double* x, const int* stop, hipStream_t stream, bool inCG)
+// pushOnly: the consumer (pattern SpMV, HALO instantiation) waits for the flags and reads the staging area itself.
+static void halo_exchange(sb_halo* h, double* x, const int* stop, hipStream_t stream, bool inCG, bool pushOnly)
 {
   if (!h || g.size == 1) return;
   if (!stream) stream = g.stream;
@@ -440,7 +442,7 @@ static void halo_exchange(sb_halo* h, double* x, const int* stop, hipStream_t st
     const unsigned long long seq = ++h->seq;
     if (h->totalSend)
       hipLaunchKernelGGL(halo_push_k, dim3(stream_grid(h->totalSend, 256)), dim3(256), 0, stream, h->push, x, seq, stop);
-    if (h->indegree)
+    if (h->indegree && !pushOnly)
       hipLaunchKernelGGL(halo_pull_k, dim3(h->indegree), dim3(256), 0, stream, h->dSrcRank, h->dRdispl, h->dRcount,
           h->stage, h->stage + 2 * (size_t)h->externalCount, (uint32_t)h->externalCount, x + h->nr, seq, h->err, stop);
     HIP_CHECK(hipGetLastError());

@@ -19,16 +19,17 @@ static bool spmv_can_split(const sb_matrix* m)
   return spmv_uses_patterns(m) && pm->patInterior > 0 && pm->patInterior < (pm->nChunks + 3) / 4;
 }
 static void launch_pat(const sb_matrix* pm, bool skipPad, const double* x, double* y, double* dotPartials,
-    const int* stop, int part, hipStream_t stream);
+    const int* stop, int part, hipStream_t stream, const HaloWait* halo);
 
+// halo != NULL (pattern kernel only): the halo-touching tiles wait for the neighbours' pushes themselves
 static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* dotPartials,
-    const int* stop, int part = 0, hipStream_t stream = nullptr)
+    const int* stop, int part = 0, hipStream_t stream = nullptr, const HaloWait* halo = nullptr)
 {
   const bool dot = dotPartials != nullptr;
   if (m->nr == 0) return;
   if (part != 0 && !spmv_can_split(m)) SB_FATAL("this SpMV kernel cannot be launched in parts");
   if (m->fmt == 0 && spmv_uses_patterns(m)) {
-    launch_pat(m->mirror, true, x, y, dotPartials, stop, part, stream ? stream : g.stream);
+    launch_pat(m->mirror, true, x, y, dotPartials, stop, part, stream ? stream : g.stream, halo);
   } else if (m->fmt == 0) {
     if (dot) SB_FATAL("fused dot needs the pattern kernel (SCS C=64, or CRS through its mirror)");
     const uint32_t per = (m->nRowBlocks + 7) / 8;
@@ -47,7 +48,7 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
     const uint32_t per     = g_scs_xcd ? (nBlocks + 7) / 8 : 0;
     dim3 grid(g_scs_xcd ? per * 8 : nBlocks), block(256);
     if (m->usePacked == 3) {
-      launch_pat(m, false, x, y, dotPartials, stop, part, stream ? stream : g.stream);
+      launch_pat(m, false, x, y, dotPartials, stop, part, stream ? stream : g.stream, halo);
     } else if (m->usePacked == 2) {
       const size_t shmem = (256 + (size_t)m->ldsWindow) * sizeof(double);
 #define LDS_LAUNCH(DI, DO)                                                                                   \
@@ -102,8 +103,11 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
 }
 
 static void launch_pat(const sb_matrix* pm, bool skipPad, const double* x, double* y, double* dotPartials,
-    const int* stop, int part, hipStream_t stream)
+    const int* stop, int part, hipStream_t stream, const HaloWait* halo)
 {
+  HaloWait hw;
+  memset(&hw, 0, sizeof hw);
+  if (halo) hw = *halo;
   const bool dot         = dotPartials != nullptr;
   const uint32_t nBlocks = (pm->nChunks + 3) / 4;
   const size_t shmem = ((size_t)pm->patDict + pm->patExcLds + 8) * sizeof(PatEntry) + (size_t)pm->ldsWindow * sizeof(double);
@@ -112,17 +116,23 @@ static void launch_pat(const sb_matrix* pm, bool skipPad, const double* x, doubl
   const uint32_t count = part == 1 ? pm->patInterior : part == 2 ? nBlocks - pm->patInterior : nBlocks;
   const uint32_t pper  = g_scs_xcd ? (count + 7) / 8 : 0;
   const dim3 pgrid(g_scs_xcd ? pper * 8 : count), block(256);
-#define PAT_LAUNCH(DO, SK)                                                                                       \
-  hipLaunchKernelGGL((spmv_scs64_pat<DO, SK>), pgrid, block, shmem, stream, pm->tileHdrs, pm->jcodes, pm->rowBase, \
-      pm->classDict, pm->rowPats, pm->excRows, pm->tileSegs, x, y, pm->nr, pm->nChunks, first, count, pper,      \
-      pm->padCol, pm->patDict, pm->patExcLds, dotPartials, stop)
+#define PAT_LAUNCH(DO, SK, HA)                                                                                   \
+  hipLaunchKernelGGL((spmv_scs64_pat<DO, SK, HA>), pgrid, block, shmem, stream, pm->tileHdrs, pm->jcodes, pm->rowBase, \
+      pm->classDict, pm->rowPats, pm->excRows, pm->tileSegs, x, y, pm->nr, pm->nChunks, first, count, pper,           \
+      pm->padCol, pm->patDict, pm->patExcLds, dotPartials, stop, hw)
+#define PAT_PICK(SK, HA)                \
+  do {                                  \
+    if (dot) PAT_LAUNCH(true, SK, HA);  \
+    else PAT_LAUNCH(false, SK, HA);     \
+  } while (0)
   if (skipPad) {
-    if (dot) PAT_LAUNCH(true, true);
-    else PAT_LAUNCH(false, true);
+    if (halo) PAT_PICK(true, true);
+    else PAT_PICK(true, false);
   } else {
-    if (dot) PAT_LAUNCH(true, false);
-    else PAT_LAUNCH(false, false);
+    if (halo) PAT_PICK(false, true);
+    else PAT_PICK(false, false);
   }
+#undef PAT_PICK
 #undef PAT_LAUNCH
   HIP_CHECK(hipGetLastError());
 }

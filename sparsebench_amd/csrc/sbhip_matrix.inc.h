@@ -441,7 +441,9 @@ static size_t pattern_headers(sb_matrix* m, const PatternPlan& P)
       }
       return false;
     };
-    auto mid = std::stable_partition(hdrs.begin(), hdrs.end(), [&](const TileHdr& h) { return !touches_halo(h); });
+    for (TileHdr& h : hdrs)
+      if (touches_halo(h)) h.flags |= PAT_TOUCHES_HALO;
+    auto mid = std::stable_partition(hdrs.begin(), hdrs.end(), [&](const TileHdr& h) { return !(h.flags & PAT_TOUCHES_HALO); });
     m->patInterior = (uint32_t)(mid - hdrs.begin());
   }
   m->tileHdrs = (TileHdr*)upload(hdrs.data(), hdrs.size() * sizeof(TileHdr));

@@ -34,8 +34,9 @@ def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax, p2p):
     """p2p=1: the dot all-reduces happen inside the scalar step over peer-mapped (IPC) memory when the
     ranks' kernels really run concurrently on the one GPU (otherwise the self-test falls back, which the
     worker reports); p2p=0: local reduce | transport all-reduce | scalar step.  Same bits either way."""
-    # the halo overlap (second stream, fork/join) rides along: on with p2p=1, off (the default) with p2p=0
-    env = dict(os.environ, OMP_NUM_THREADS="1", SB_P2P=p2p, SB_P2P_REPORT="1", SB_HALO_OVERLAP=p2p)
+    # p2p=1 (the default set-up): push kernel + SpMV whose halo-touching tiles wait for the flags themselves;
+    # p2p=0: transport send-recv, and the two-stream halo overlap (off by default) rides along to keep it covered
+    env = dict(os.environ, OMP_NUM_THREADS="1", SB_P2P=p2p, SB_P2P_REPORT="1", SB_HALO_OVERLAP="1" if p2p == "0" else "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(size),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "gpu_multirank_worker.py"), fmt, str(Cc), str(sigma), str(n), str(itermax)]

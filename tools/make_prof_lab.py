@@ -26,10 +26,10 @@ def patch(path, pairs):
 
 
 patch(W + "/sparsebench_amd/csrc/pack.hip.h", [
-    ("template <bool DOT, bool SKIPPAD>\n__global__ __launch_bounds__(256) void spmv_scs64_pat(",
+    ("template <bool DOT, bool SKIPPAD, bool HALO>\n__global__ __launch_bounds__(256) void spmv_scs64_pat(",
      "__device__ long long g_prof[8192 * 8];\n"
      "#define PROF(i) do { if (((PROF_POINTS) >> (i)) & 1) if (threadIdx.x == 0 && blockIdx.x < 8192) g_prof[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)\n"
-     "template <bool DOT, bool SKIPPAD>\n__global__ __launch_bounds__(256) void spmv_scs64_pat("),
+     "template <bool DOT, bool SKIPPAD, bool HALO>\n__global__ __launch_bounds__(256) void spmv_scs64_pat("),
     ("  // A launch covers headers [firstHdr", "  PROF(0);\n  // A launch covers headers [firstHdr"),
     ("  const int stopped    = (int)field(PAT_STOP_LANE);\n", "  const int stopped    = (int)field(PAT_STOP_LANE);\n  PROF(1);\n"),
     ("  if (tile0 >= nHdrs || stopped) return; // uniform per workgroup\n",
