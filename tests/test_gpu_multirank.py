@@ -28,6 +28,7 @@ def _free_port():
     ("scs", 64, 1, 16, 4, 100),     # interior ranks with two neighbours
     ("crs", 64, 1, 16, 2, 100),
     ("scs", 4, 8, 8, 3, 40),        # generic-C kernel, odd rank count
+    ("scs", 64, 1, 48, 3, 150),     # several tiles per rank, many exchanges: staging-area parity, flags, row patterns
 ])
 @pytest.mark.parametrize("p2p", ["1", "0"])
 def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax, p2p):
