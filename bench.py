@@ -176,7 +176,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane only (id broadcast, barriers, max of the timings); the data
         # plane -- halo and dot all-reduce -- is RCCL inside the HIP layer
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        with quiet_stdout():  # gloo announces its connections on stdout; rank 0's stdout carries ONE JSON line
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
 
     from sparsebench_amd import capi, hostapi
     capi.load()
