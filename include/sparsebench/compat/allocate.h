@@ -1,0 +1,9 @@
+/* allocate.h -- forwarding header: lets a source file written against the reference's
+ * own "allocate.h" (src/allocate.h:9) compile unchanged against the MI355X drop-in.
+ * Build the caller with -I<repo>/include/sparsebench/compat -DCRS|-DSCS and link
+ * libsparsebench_<fmt>.so.  Everything lives in sparsebench.h. */
+#ifndef SPARSEBENCH_COMPAT_ALLOCATE_H
+#define SPARSEBENCH_COMPAT_ALLOCATE_H
+#include "../sparsebench.h"
+#include <stdlib.h>
+#endif

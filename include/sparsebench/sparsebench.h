@@ -40,6 +40,24 @@ extern "C" {
 #define ARRAY_ALIGNMENT 64 /* config.mk:11 */
 #endif
 #define HLINE "----------------------------------------------------------------------\n"
+/* src/util.h:13-33 */
+#ifndef MIN
+#define MIN(x, y) ((x) < (y) ? (x) : (y))
+#endif
+#ifndef MAX
+#define MAX(x, y) ((x) > (y) ? (x) : (y))
+#endif
+#ifndef ABS
+#define ABS(a) ((a) >= 0 ? (a) : -(a))
+#endif
+#ifndef IS_EQUAL
+#define IS_EQUAL(a, b) (strcmp((a), (b)) == 0)
+#endif
+#ifndef MAXLINE
+#define MAXLINE 4096
+#endif
+/* src/util.h:55, src/util.c:11-32: "<name up to its last dot><newEnding>", malloc'ed */
+char* changeFileEnding(char* filename, char* newEnding);
 #define MAX_EXTERNAL 6000000 /* src/comm.h:16 -- kept for source compatibility only */
 
 /* ---- run-time parameters: src/parameter.h:9-18 ---------------------------------- */
@@ -170,6 +188,9 @@ void commFinalize(Comm* c);
 void commDistributeMatrix(Comm* c, MMMatrix* m, MMMatrix* mLocal);
 void commPartition(Comm* c, GMatrix* m);
 void commPrintConfig(Comm* c, CG_UINT nr, CG_UINT nnz, CG_UINT startRow, CG_UINT stopRow);
+/* diagnostics of the VERBOSE build, src/comm.h:54-56 (write to c->logFile when it is open) */
+void commGMatrixDump(Comm* c, GMatrix* m);
+void commVectorDump(Comm* c, CG_FLOAT* v, CG_UINT size, char* name); /* v: host or device */
 void commExchange(Comm* c, CG_UINT numRows, CG_FLOAT* x); /* x: DEVICE vector of nc entries */
 void commReduction(CG_FLOAT* v, int op);                   /* v: host or device scalar */
 void commPrintBanner(Comm* c);
@@ -183,14 +204,21 @@ void matrixConvertfromMM(MMMatrix* mm, GMatrix* m);
 void matrixGenerate(GMatrix* m, Parameter* p, int rank, int size, bool use_7pt_stencil);
 /* binary matrix files, src/matrixBinfile.h:21-22 (same bytes; plain POSIX I/O instead of MPI-IO;
  * SB_BMX_FP64=1 writes the fp64 extension, the reader accepts both) */
+typedef struct { /* src/matrixBinfile.h:10-13: one stored nonzero of a .bmx file */
+  unsigned int col;
+  float val;
+} FEntry;
 void matrixBinWrite(GMatrix* m, Comm* c, char* filename);
 void matrixBinRead(GMatrix* m, Comm* c, char* filename);
 /* the driver's matrix set-up, src/main.c:54-84 (generate | generate7P | .mtx | .bmx), and its
  * `-c file.mtx` conversion, src/main.c:41-52 */
 void sbh_init_matrix(Comm* c, Parameter* p, GMatrix* m);
+/* commDistributeMatrix for a driver in which EVERY rank has read the file: keeps this rank's rows in place */
+void sbh_distribute_local(Comm* c, MMMatrix* m, MMMatrix* mLocal);
 void sbh_write_bin_matrix(Comm* c, char* mtxFilename);
 void* allocate(size_t alignment, size_t bytesize); /* src/allocate.h:9 (host memory) */
-double getTimeStamp(void);                          /* src/timing.h */
+double getTimeStamp(void);                          /* src/timing.h:8 */
+double getTimeResolution(void);                     /* src/timing.h:9 */
 
 /* runtime-format entry points (what the drop-in symbols below forward to) */
 void sbh_convert_crs(CRSMatrix* m, GMatrix* im);
@@ -206,6 +234,7 @@ int solveCG(Comm* comm, Parameter* param, Matrix* m);
 /* x (nc entries) and y (nr entries) may be device or host pointers; host pointers are
  * staged through HBM (correct, slow: use sb_malloc'ed vectors on the hot path) */
 void spMVM(Matrix* m, const CG_FLOAT* restrict x, CG_FLOAT* restrict y);
+void commMatrixDump(Comm* c, Matrix* m); /* src/comm.h:55 */
 #endif
 void waxpby(const CG_UINT n, const CG_FLOAT alpha, const CG_FLOAT* restrict x,
             const CG_FLOAT beta, const CG_FLOAT* restrict y,

@@ -23,6 +23,8 @@
 #                         cpu_baseline "reference" leg of bench.py (timing only)
 #   sb_ref_mpi            full reference (main.c, MPI) for multi-rank golden
 #                         histories, only if an MPI compiler wrapper is present
+#   refmain_{CRS,SCS}_hip the reference's main.c (unchanged) linked with OUR drop-in
+#                         libraries instead of the reference's objects
 set -euo pipefail
 REF=${SB_REFERENCE:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -64,5 +66,18 @@ if [ -x "$MPICC" ]; then
     -I"$S" -o "$OUT/sb_ref_mpi" "$HERE/ref_mpi_log.c" $S/main.c $COMMON "$S/matrix-CRS.c" \
     "$S/matrixBinfile.c" "$S/parameter.c" "$S/affinity.c" -Wl,--wrap=ddot -Wl,-Bsymbolic -lm \
     || echo "build_ref: MPI variant failed (non-fatal)" >&2
+fi
+# The reference's OWN driver, unchanged, on top of the MI355X drop-in: src/main.c compiled against the
+# forwarding headers (include/sparsebench/compat) and linked with libsparsebench_<fmt>.so -- no reference
+# object besides main.o.  Lets the GPU box RUN "main.c drives it" (tests/test_gpu_dropin.py).
+REPO=$(cd "$HERE/.." && pwd)
+if [ -f "$REPO/sparsebench_amd/lib/libsparsebench_crs.so" ]; then
+  for F in CRS SCS; do
+    f=$(echo $F | tr A-Z a-z)
+    gcc -std=gnu11 -O1 -w -D$F -DPRECISION=2 -DUINT_TYPE=1 -DARRAY_ALIGNMENT=64 \
+      -I"$REPO/include/sparsebench/compat" -I"$REPO/include" "$S/main.c" -o "$OUT/refmain_${F}_hip" \
+      -L"$REPO/sparsebench_amd/lib" -lsparsebench_$f -lsparsebench_host -lsbhip \
+      -Wl,-rpath,'$ORIGIN/../../sparsebench_amd/lib' -lm || echo "build_ref: refmain_$F failed (non-fatal)" >&2
+  done
 fi
 ls -la "$OUT"

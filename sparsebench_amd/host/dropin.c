@@ -54,3 +54,15 @@ void spMVM(Matrix* m, const CG_FLOAT* restrict x, CG_FLOAT* restrict y)
 {
   sbh_spmv(m->dev, m->nr, m->nc, x, y);
 }
+
+/* src/comm.h:55 (VERBOSE-build diagnostic): scalars of the converted matrix */
+void commMatrixDump(Comm* c, Matrix* m)
+{
+  FILE* f = c->logFile ? c->logFile : stdout;
+  fprintf(f, "Matrix (%s): rank %d, nr %u nc %u nnz %u totalNr %u totalNnz %u rows %u..%u\n", FMT, c->rank, m->nr,
+      m->nc, m->nnz, m->totalNr, m->totalNnz, m->startRow, m->stopRow);
+#if defined(SCS)
+  fprintf(f, "C %u sigma %u nrPadded %u nChunks %u nElems %u\n", m->C, m->sigma, m->nrPadded, m->nChunks, m->nElems);
+#endif
+  fflush(f);
+}

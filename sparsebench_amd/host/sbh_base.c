@@ -33,6 +33,16 @@ double getTimeStamp(void)
   return (double)t.tv_sec + 1.e-9 * (double)t.tv_nsec;
 }
 
+/* src/timing.c:15-28: smallest observable step of getTimeStamp() */
+double getTimeResolution(void)
+{
+  struct timespec t;
+  if (clock_getres(CLOCK_MONOTONIC, &t) == 0) return (double)t.tv_sec + 1.e-9 * (double)t.tv_nsec;
+  double a = getTimeStamp(), b;
+  while ((b = getTimeStamp()) == a) {}
+  return b - a;
+}
+
 /* src/parameter.c:12-20: defaults generate,100,100,100,150,0.0 */
 void initParameter(Parameter* p)
 {

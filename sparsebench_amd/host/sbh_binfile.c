@@ -24,11 +24,6 @@
 #define BMX_HEADERSIZE 24
 static const char BMX_MAGIC[] = "# SparseBench DataFile"; /* 22 characters */
 
-typedef struct {
-  unsigned int col;
-  float val;
-} FEntry;
-
 static void die(const char* what, const char* filename)
 {
   fprintf(stderr, "ERROR: %s: %s\n", what, filename);
@@ -150,8 +145,8 @@ void sbh_init_matrix(Comm* c, Parameter* p, GMatrix* m)
     MMMatrix mm, local;
     memset(&mm, 0, sizeof mm), memset(&local, 0, sizeof local);
     if (commIsMaster(c)) printf("Read MTX matrix\n");
-    MMMatrixRead(&mm, p->filename);
-    commDistributeMatrix(c, &mm, &local);
+    MMMatrixRead(&mm, p->filename); /* every rank reads: no scatter needed */
+    sbh_distribute_local(c, &mm, &local);
     matrixConvertfromMM(&local, m);
     free(mm.entries);
   } else if (dot && strcmp(dot, ".bmx") == 0) {
@@ -163,21 +158,28 @@ void sbh_init_matrix(Comm* c, Parameter* p, GMatrix* m)
   }
 }
 
-/* src/main.c:41-52 with util.c's changeFileEnding: file.mtx -> file.bmx */
+/* src/util.c:11-32: the name up to its last dot (all of it if there is none) + newEnding; the
+ * caller owns the malloc'ed result */
+char* changeFileEnding(char* filename, char* newEnding)
+{
+  const char* dot  = strrchr(filename, '.');
+  const size_t len = dot ? (size_t)(dot - filename) : strlen(filename);
+  char* out        = (char*)malloc(len + strlen(newEnding) + 1);
+  memcpy(out, filename, len);
+  strcpy(out + len, newEnding);
+  return out;
+}
+
+/* src/main.c:41-52: file.mtx -> file.bmx */
 void sbh_write_bin_matrix(Comm* c, char* mtxFilename)
 {
   MMMatrix mm, local;
   GMatrix m;
   memset(&mm, 0, sizeof mm), memset(&local, 0, sizeof local), memset(&m, 0, sizeof m);
   MMMatrixRead(&mm, mtxFilename);
-  commDistributeMatrix(c, &mm, &local);
+  sbh_distribute_local(c, &mm, &local);
   matrixConvertfromMM(&local, &m);
-  const size_t n = strlen(mtxFilename);
-  char* out      = (char*)malloc(n + 8);
-  memcpy(out, mtxFilename, n + 1);
-  char* dot = strrchr(out, '.');
-  if (!dot) dot = out + n;
-  strcpy(dot, ".bmx");
+  char* out = changeFileEnding(mtxFilename, ".bmx");
   matrixBinWrite(&m, c, out);
   free(out), free(mm.entries);
 }

@@ -148,6 +148,36 @@ void commPrintConfig(Comm* c, CG_UINT nr, CG_UINT nnz, CG_UINT startRow, CG_UINT
       c->outdegree);
 }
 
+/* VERBOSE-build diagnostics (src/comm.c:664-861 print the same content into out-<rank>.txt) */
+void commGMatrixDump(Comm* c, GMatrix* m)
+{
+  FILE* f = c->logFile ? c->logFile : stdout;
+  fprintf(f, "Matrix: %u total non zeroes, total number of rows %u\n", m->totalNnz, m->totalNr);
+  fprintf(f, "Matrix: %u local non zeroes, local number of rows %u (%u..%u)\n", m->rowPtr ? m->rowPtr[m->nr] : 0u,
+      m->nr, m->startRow, m->stopRow);
+  for (CG_UINT i = 0; i < m->nr; i++) {
+    fprintf(f, "Row [%u]: ", i);
+    for (CG_UINT j = m->rowPtr[i]; j < m->rowPtr[i + 1]; j++) fprintf(f, "[%u]:%.2f ", m->entries[j].col, m->entries[j].val);
+    fprintf(f, "\n");
+  }
+  fflush(f);
+}
+
+void commVectorDump(Comm* c, CG_FLOAT* v, CG_UINT size, char* name)
+{
+  FILE* f      = c->logFile ? c->logFile : stdout;
+  CG_FLOAT* h  = v;
+  if (sb_is_initialized() && sb_is_device_ptr(v)) {
+    h = (CG_FLOAT*)malloc(((size_t)size + 1) * sizeof(CG_FLOAT));
+    sb_sync();
+    sb_d2h(h, v, (size_t)size * sizeof(CG_FLOAT));
+  }
+  fprintf(f, "Vector %s Rank %d\n", name, c->rank);
+  for (CG_UINT i = 0; i < size; i++) fprintf(f, "element[%u] %f\n", i, h[i]);
+  fflush(f);
+  if (h != v) free(h);
+}
+
 /* ---- row split of file matrices: src/comm.c:35-38, :347-361 -------------------------- */
 static void rows_of_rank(int rank, int size, int N, int* first, int* last)
 {
@@ -156,9 +186,9 @@ static void rows_of_rank(int rank, int size, int N, int* first, int* last)
   *last  = *first + base + (rank < extra ? 1 : 0) - 1;
 }
 
-/* Every rank has read the file (MMMatrixRead) -- there is no scatter; a rank keeps
- * the entries of its own row range.  One rank: alias, as src/comm.c:404-411. */
-void commDistributeMatrix(Comm* c, MMMatrix* m, MMMatrix* mLocal)
+/* Every rank holds the whole file (our own driver: each rank calls MMMatrixRead) -- a rank
+ * keeps the entries of its own row range.  One rank: alias, as src/comm.c:404-411. */
+void sbh_distribute_local(Comm* c, MMMatrix* m, MMMatrix* mLocal)
 {
   int first, last;
   rows_of_rank(c->rank, c->size, m->nr, &first, &last);
@@ -182,6 +212,64 @@ void commDistributeMatrix(Comm* c, MMMatrix* m, MMMatrix* mLocal)
   mLocal->nr       = last - first + 1;
   mLocal->totalNr  = m->nr;
   mLocal->totalNnz = m->nnz;
+}
+
+/* The reference's contract (src/comm.c:311-402, src/main.c:63-70): ONLY the master has read the
+ * file; the other ranks pass an uninitialised MMMatrix.  So with several ranks the master's
+ * header and entries are authoritative: they travel over the setup exchange in bounded pieces
+ * (an all-gather in which only the master's slice is looked at) and every rank keeps the entries
+ * of its row range (reference: MPI_Bcast of the counts + MPI_Scatterv of the entries). */
+void commDistributeMatrix(Comm* c, MMMatrix* m, MMMatrix* mLocal)
+{
+  if (c->size == 1) {
+    sbh_distribute_local(c, m, mLocal);
+    return;
+  }
+  if (!g_xchg) {
+    fprintf(stderr, "commDistributeMatrix: %d ranks but no setup exchange (commSetExchange)\n", c->size);
+    exit(EXIT_FAILURE);
+  }
+  const int P = c->size;
+  int hdr[4] = { 0, 0, 0, 0 }; /* nr, nnz, count (lo, hi 31-bit halves) */
+  if (commIsMaster(c)) hdr[0] = m->nr, hdr[1] = m->nnz, hdr[2] = (int)(m->count & 0x7FFFFFFF), hdr[3] = (int)(m->count >> 31);
+  int* allHdr = (int*)malloc((size_t)P * 4 * sizeof(int));
+  g_xchg->allgather_ints(g_xchg->ctx, hdr, 4, allHdr);
+  const int totalNr = allHdr[0], totalNnz = allHdr[1];
+  const size_t count = (size_t)allHdr[2] | ((size_t)allHdr[3] << 31);
+  free(allHdr);
+  int first, last;
+  rows_of_rank(c->rank, P, totalNr, &first, &last);
+  if (commIsMaster(c))
+    for (int r = 0; r < P; r++) {
+      int a, b;
+      rows_of_rank(r, P, totalNr, &a, &b);
+      printf("Rank %d start %d stop %d\n", r, a, b);
+    }
+  const size_t PIECE = 1u << 20; /* entries per piece: 16 MiB per rank slice */
+  int* mine   = (int*)calloc(PIECE * 4, sizeof(int));
+  int* all    = (int*)malloc((size_t)P * PIECE * 4 * sizeof(int));
+  size_t cap  = 1024, used = 0;
+  MMEntry* keep = (MMEntry*)malloc(cap * sizeof(MMEntry));
+  for (size_t at = 0; at < count; at += PIECE) {
+    const size_t n = count - at < PIECE ? count - at : PIECE;
+    if (commIsMaster(c)) memcpy(mine, m->entries + at, n * sizeof(MMEntry));
+    g_xchg->allgather_ints(g_xchg->ctx, mine, (int)(n * 4), all);
+    const MMEntry* e = (const MMEntry*)all; /* rank 0's slice comes first */
+    for (size_t i = 0; i < n; i++)
+      if (e[i].row >= first && e[i].row <= last) {
+        if (used == cap) keep = (MMEntry*)realloc(keep, (cap *= 2) * sizeof(MMEntry));
+        keep[used++] = e[i];
+      }
+  }
+  free(mine), free(all);
+  mLocal->entries  = keep;
+  mLocal->count    = used;
+  mLocal->nnz      = (int)used;
+  mLocal->startRow = first;
+  mLocal->stopRow  = last;
+  mLocal->nr       = last - first + 1;
+  mLocal->totalNr  = totalNr;
+  mLocal->totalNnz = totalNnz;
 }
 
 /* ---- partition + halo plan --------------------------------------------------------- */

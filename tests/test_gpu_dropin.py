@@ -18,8 +18,8 @@ LIB = os.path.join(ROOT, "sparsebench_amd", "lib")
 BIN = os.path.join(ROOT, "sparsebench_amd", "bin")
 
 
-def build_driver(fmt):
-    exe = os.path.join(ROOT, "tests", "c", "dropin_driver_%s" % fmt)
+def build_driver(fmt, outdir):
+    exe = os.path.join(str(outdir), "dropin_driver_%s" % fmt)
     cmd = ["gcc", "-std=gnu11", "-O1", "-D" + fmt, "-I" + os.path.join(ROOT, "include"),
            os.path.join(ROOT, "tests", "c", "dropin_driver.c"), "-o", exe, "-L" + LIB,
            "-lsparsebench_%s" % fmt.lower(), "-lsparsebench_host", "-lsbhip", "-Wl,-rpath," + LIB, "-lm"]
@@ -29,8 +29,8 @@ def build_driver(fmt):
 
 @pytest.mark.parametrize("fmt", ["CRS", "SCS"])
 @pytest.mark.parametrize("inp", ["generate", "matrix_band_klein"])
-def test_reference_shaped_c_caller(gpu, fmt, inp):
-    exe = build_driver(fmt)
+def test_reference_shaped_c_caller(gpu, fmt, inp, tmp_path):
+    exe = build_driver(fmt, tmp_path)
     arg = "generate" if inp == "generate" else os.path.join(REFDATA, inp + ".mtx")
     out = subprocess.run([exe, arg], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
@@ -56,7 +56,7 @@ def test_reference_shaped_c_caller(gpu, fmt, inp):
     assert "Function   Rate(MB/s)  Rate(MFlop/s)  Walltime(s)" in txt
 
 
-def test_benchmark_executable_cli(gpu, golden_1rank):
+def test_benchmark_executable_cli(gpu, golden_1rank, tmp_path):
     """sparseBench-<FMT>-HIP: the reference's flags and output lines"""
     for exe, extra in (("sparseBench-CRS-HIP", []), ("sparseBench-SCS-HIP", ["-C", "64", "-s", "256"])):
         out = subprocess.run([os.path.join(BIN, exe), "-x", "32", "-y", "32", "-z", "32", "-i", "50"] + extra,
@@ -75,7 +75,7 @@ def test_benchmark_executable_cli(gpu, golden_1rank):
     out = subprocess.run([os.path.join(BIN, "sparseBench-SCS-HIP"), "-t", "spmv", "-x", "32", "-y", "32",
                           "-z", "32", "-i", "20"], stdout=subprocess.PIPE, timeout=300)
     assert out.returncode == 0 and "Test type: SPMVM" in out.stdout.decode()
-    par = os.path.join(ROOT, "tests", "c", "small.par")
+    par = str(tmp_path / "small.par")
     open(par, "w").write("filename generate #Space is required after string!\nnx 8\nny 8\nnz 8\nitermax 20\neps 0.0\n")
     out = subprocess.run([os.path.join(BIN, "sparseBench-CRS-HIP"), "-f", par], stdout=subprocess.PIPE, timeout=300)
     assert "Initial Residual = 2.084418E+02" in out.stdout.decode()  # BASELINE.md, HPCG 8^3
@@ -100,3 +100,43 @@ def test_driver_binary_matrix_files(gpu, tmp_path):
         runs.append([re.sub(r" and took .*", "", ln) for ln in r.stdout.decode().splitlines()
                      if ln.startswith(("Initial Residual", "Iteration =", "Solution performed", "Difference"))])
     assert runs[0] == runs[1] and any("Solution performed 3 iterations" in ln for ln in runs[0]), runs
+
+
+REFMAIN = os.path.join(ROOT, "oracle", "_ref")
+
+
+@pytest.mark.parametrize("fmt", ["CRS", "SCS"])
+def test_reference_main_c_drives_the_hip_path(gpu, fmt, golden_1rank, tmp_path):
+    """oracle/_ref/refmain_<FMT>_hip = the reference's src/main.c, NOT ONE LINE CHANGED, compiled in the build
+    container against include/sparsebench/compat and linked with libsparsebench_<fmt>.so (oracle/build_ref.sh).
+    Its command line, its output lines and its numbers are the reference's; the arithmetic ran on the GPU."""
+    exe = os.path.join(REFMAIN, "refmain_%s_hip" % fmt)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/refmain_%s_hip was not built (needs /root/reference in the build container)" % fmt)
+    env = dict(os.environ, SPARSEBENCH_C="64", SPARSEBENCH_SIGMA="128")
+    out = subprocess.run([exe, "-x", "32", "-y", "32", "-z", "32", "-i", "50"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    txt = out.stdout.decode()
+    rr = np.array([float(v) for v in golden_1rank["hpcg32"]["rr"]])
+    assert "Using %s matrix format, double precision floats and integer type unsigned int" % fmt in txt
+    assert "Test type: CG" in txt and "Initial Residual = %E" % np.sqrt(rr[0]) in txt
+    for k in (5, 10, 15, 20, 25, 30):
+        assert "Iteration = %d Residual = %E" % (k, np.sqrt(rr[k - 1])) in txt, k
+    assert "Solution performed 50 iterations" in txt and "Difference between computed and exact  = 0.000000" in txt
+    assert "Function   Rate(MB/s)  Rate(MFlop/s)  Walltime(s)" in txt
+    # -m file.mtx (config 1) and -t spmv with the driver's own HOST vectors (src/main.c:205-215)
+    klein = os.path.join(REFDATA, "matrix_band_klein.mtx")
+    out = subprocess.run([exe, "-m", klein], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    assert out.returncode == 0 and "Initial Residual = 1.000000E+01" in out.stdout.decode()
+    assert "Solution performed 3 iterations" in out.stdout.decode()
+    out = subprocess.run([exe, "-t", "spmv", "-x", "16", "-y", "16", "-z", "16", "-i", "10"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=300, env=env)
+    assert out.returncode == 0 and "Test type: SPMVM" in out.stdout.decode(), out.stderr.decode()[-2000:]
+    # -c file.mtx: the driver's writeBinMatrix path (changeFileEnding + matrixBinWrite) gives the reference's bytes
+    import shutil
+    mtx = tmp_path / "matrix_band_klein.mtx"
+    shutil.copy(klein, mtx)
+    subprocess.run([exe, "-c", str(mtx)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    golden = open(os.path.join(REFDATA, "matrix_band_klein.bmx"), "rb").read()
+    assert open(tmp_path / "matrix_band_klein.bmx", "rb").read() == golden
