@@ -162,6 +162,9 @@ void sb_comm_init_transport(int rank, int size, const sb_transport* t);
 int sb_comm_p2p_handle(unsigned char* handle_out);
 int sb_comm_p2p_open(const unsigned char* all_handles); /* NULL: this rank has no handle */
 int sb_comm_p2p_enabled(void);
+/* one line saying why the path is on or off (which rank, which call failed, what the self-test saw);
+ * waits inside CG are bounded by SB_P2P_TIMEOUT_MS (default 30000), the set-up self-tests by 2 s */
+const char* sb_comm_p2p_reason(void);
 void sb_comm_finalize(void);
 int sb_comm_rank(void);
 int sb_comm_size(void);
@@ -187,6 +190,7 @@ void sb_halo_free(sb_halo* h);
  * collectively in sb_halo_create when the in-kernel all-reduce is on; SB_P2P_HALO=0 disables), 0: RCCL /
  * transport send-recv */
 int sb_halo_p2p_enabled(const sb_halo* h);
+const char* sb_halo_p2p_reason(const sb_halo* h);
 /* commExchange, src/comm.h:57: pack x[elementsToSend] and deliver every
  * neighbour's slice into x[numRows ...]; stream-ordered */
 void sb_halo_exchange(sb_halo* h, double* x);

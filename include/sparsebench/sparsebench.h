@@ -202,6 +202,10 @@ void commBarrier(void);
 void MMMatrixRead(MMMatrix* m, char* filename);
 void matrixConvertfromMM(MMMatrix* mm, GMatrix* m);
 void matrixGenerate(GMatrix* m, Parameter* p, int rank, int size, bool use_7pt_stencil);
+/* "irregular": deterministic irregular SPD FE-like matrix of 3*nx*ny*nz rows, the committed stand-in for
+ * SuiteSparse Flan_1565 (BASELINE configs[4]; host/sbh_irregular.c).  Enters like a .mtx file: global
+ * column ids, rows split over ranks by the file rule (src/comm.c:35-38), b = 1. */
+void sbh_matrix_generate_irregular(GMatrix* m, Parameter* p, int rank, int size);
 /* binary matrix files, src/matrixBinfile.h:21-22 (same bytes; plain POSIX I/O instead of MPI-IO;
  * SB_BMX_FP64=1 writes the fp64 extension, the reader accepts both) */
 typedef struct { /* src/matrixBinfile.h:10-13: one stored nonzero of a .bmx file */

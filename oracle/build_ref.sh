@@ -23,6 +23,7 @@
 #                         cpu_baseline "reference" leg of bench.py (timing only)
 #   sb_ref_mpi            full reference (main.c, MPI) for multi-rank golden
 #                         histories, only if an MPI compiler wrapper is present
+#   sb_ref_mpi_omp        full reference, upstream flags -O3 -ffast-math + OpenMP + MPI (timing only)
 #   refmain_{CRS,SCS}_hip the reference's main.c (unchanged) linked with OUR drop-in
 #                         libraries instead of the reference's objects
 set -euo pipefail
@@ -67,6 +68,15 @@ if [ -x "$MPICC" ]; then
     "$S/matrixBinfile.c" "$S/parameter.c" "$S/affinity.c" -Wl,--wrap=ddot -Wl,-Bsymbolic -lm \
     || echo "build_ref: MPI variant failed (non-fatal)" >&2
 fi
+# the same full reference with upstream optimisation flags + OpenMP (MPI ranks x OpenMP threads: the hybrid mode
+# north_star names for the CPU baseline; bench.py's cpu_baseline.mpi_openmp leg, timing only)
+if [ -x "$MPICC" ] && $CLANG -fopenmp -x c -o /dev/null -c - <<<'int main(void){return 0;}' 2>/dev/null; then
+  MPICH_CC=$CLANG "$MPICC" -DCRS -D_MPI -D_OPENMP $DEFS -O3 -ffast-math -fopenmp -std=c23 -w \
+    -I"$S" -o "$OUT/sb_ref_mpi_omp" $S/main.c $COMMON "$S/matrix-CRS.c" \
+    "$S/matrixBinfile.c" "$S/parameter.c" "$S/affinity.c" -lm -Wl,-rpath,/opt/rocm/lib/llvm/lib \
+    || echo "build_ref: MPI+OpenMP variant failed (non-fatal)" >&2
+fi
+
 # The reference's OWN driver, unchanged, on top of the MI355X drop-in: src/main.c compiled against the
 # forwarding headers (include/sparsebench/compat) and linked with libsparsebench_<fmt>.so -- no reference
 # object besides main.o.  Lets the GPU box RUN "main.c drives it" (tests/test_gpu_dropin.py).

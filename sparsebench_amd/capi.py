@@ -29,7 +29,7 @@ SYMBOLS = [
     "sb_cg_spmv_timing", "sb_cg_spmv_ms", "sb_cg_counters", "sb_debug_stream_read_gbs",
     "sb_matrix_pack_level", "sb_matrix_use_packed", "sb_matrix_stream_bytes",
     "sb_matrix_packed_mode", "sb_matrix_lds_window", "sb_matrix_pattern_classes", "sb_matrix_row_patterns", "sb_comm_p2p_handle", "sb_comm_p2p_open", "sb_comm_p2p_enabled", "sb_halo_p2p_enabled", "sb_cg_start", "sb_cg_finish",
-    "sb_comm_init_transport",
+    "sb_comm_init_transport", "sb_comm_p2p_reason", "sb_halo_p2p_reason",
 ]
 
 _lib = None
@@ -126,6 +126,8 @@ def load():
         "sb_comm_p2p_open": (C.c_int, [vp]),
         "sb_comm_p2p_enabled": (C.c_int, []),
         "sb_halo_p2p_enabled": (C.c_int, [vp]),
+        "sb_comm_p2p_reason": (C.c_char_p, []),
+        "sb_halo_p2p_reason": (C.c_char_p, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

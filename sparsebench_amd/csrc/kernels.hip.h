@@ -576,9 +576,13 @@ struct P2PSlot {
 };
 struct P2PView {
   int rank, size;
+  long long timeoutTicks; // bound of every wait, in wall_clock64 ticks (100 MHz); SB_P2P_TIMEOUT_MS
   P2PSlot* peer[P2P_MAX]; // peer[r]: rank r's buffer, P2PSlot[2][P2P_MAX], as mapped in this process
 };
-constexpr long long P2P_TIMEOUT_TICKS = 200000000ll; // 2 s of wall_clock64 (100 MHz)
+// A wait is bounded so that a dead peer ends the run with a message instead of hanging the GPU; the bound
+// is generous (default 30 s inside CG, SB_P2P_TIMEOUT_MS) because a merely LATE peer (first-kernel load, OS
+// jitter) must not be fatal -- RCCL would simply wait.  The set-up self-tests use 2 s.
+constexpr long long P2P_TICKS_PER_MS = 100000ll;
 
 // every thread of the workgroup calls this with the same `mine`; returns the same sum in every thread
 __device__ __forceinline__ double p2p_allreduce_sum(const P2PView* pv, double mine, unsigned long long seq,
@@ -595,7 +599,7 @@ __device__ __forceinline__ double p2p_allreduce_sum(const P2PView* pv, double mi
     const long long t0 = wall_clock64();
     bool ok            = true;
     while (__hip_atomic_load(&src->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-      if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) {
+      if (wall_clock64() - t0 > pv->timeoutTicks) {
         ok = false;
         break;
       }
@@ -653,6 +657,7 @@ struct HaloPush {
   unsigned long long* stage[P2P_MAX]; // destination i's staging area, as mapped here
   unsigned long long* flag[P2P_MAX];  // destination i's flags
   uint32_t ext[P2P_MAX];              // destination i's externalCount (area stride)
+  long long timeoutTicks;             // bound of the receivers' waits (halo_pull_k, HALO SpMV)
 };
 
 __global__ __launch_bounds__(256) void halo_push_k(HaloPush hp, const double* __restrict__ x,
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(256) void halo_push_k(HaloPush hp, const double* __
 
 __global__ __launch_bounds__(256) void halo_pull_k(const int* __restrict__ srcRank, const int* __restrict__ rdispl,
     const int* __restrict__ rcount, const unsigned long long* stage, const unsigned long long* flags,
-    uint32_t ext, double* __restrict__ xTail, unsigned long long seq, int* err, const int* __restrict__ stop)
+    uint32_t ext, double* __restrict__ xTail, unsigned long long seq, int* err, int* stop, long long timeoutTicks)
 {
   __shared__ int ok;
   if (stop && *stop) return;
@@ -692,9 +697,10 @@ __global__ __launch_bounds__(256) void halo_pull_k(const int* __restrict__ srcRa
     const long long t0          = wall_clock64();
     int good                    = 1;
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-      if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) {
+      if (wall_clock64() - t0 > timeoutTicks) {
         good = 0;
         atomicExch(err, 1);
+        if (stop) atomicExch(stop, 1); // the loop must not go on iterating on a stale halo
         break;
       }
       __builtin_amdgcn_s_sleep(4);
@@ -750,7 +756,8 @@ __global__ __launch_bounds__(1024) void cg_scalar_p2p_k(uint32_t m, const double
   if (stopped) return;
   __syncthreads(); // lds16 is reused
   total = p2p_allreduce_sum(pv, total, seq, lds16, &S->p2p_error);
-  if (S->p2p_error) { // uniform: raised before the barriers inside the exchange
+  // (atomic load: the line holding p2p_error was read for S->stop above, a plain load could be served stale)
+  if (__hip_atomic_load(&S->p2p_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // uniform: raised before the barriers inside the exchange
     if (threadIdx.x == 0) S->stop = 1;
     return;
   }

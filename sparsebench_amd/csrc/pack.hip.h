@@ -521,6 +521,8 @@ struct HaloWait {
   int nsrc;
   unsigned long long seq;
   int* err;
+  int* stopw;             // CgScalars::stop, raised together with err: no iterating on a stale halo
+  long long timeoutTicks; // bound of the wait (HaloPush::timeoutTicks)
 };
 constexpr uint32_t PAT_EXC_LDS_MAX   = 1024; // exception entries per tile (16 KiB of LDS) at most
 
@@ -642,8 +644,9 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
       const unsigned long long* f = hw.flags + (hw.seq & 1ull) * P2P_MAX + hw.src[threadIdx.x];
       const long long t0          = wall_clock64();
       while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != hw.seq) {
-        if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) {
+        if (wall_clock64() - t0 > hw.timeoutTicks) {
           atomicExch(hw.err, 1);
+          if (hw.stopw) atomicExch(hw.stopw, 1);
           break;
         }
         __builtin_amdgcn_s_sleep(4);

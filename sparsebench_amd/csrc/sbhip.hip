@@ -123,6 +123,8 @@ struct Ctx {
   P2PView* p2pView = nullptr;       // device copy of the view
   unsigned long long p2pSeq = 0;    // exchanges issued so far (identical on every rank)
   bool p2pOn = false;
+  char p2pReason[256] = "not set up (one rank, or no communicator yet)"; // why the path is on / off
+  long long p2pTimeoutTicks = 30000 * P2P_TICKS_PER_MS; // waits inside CG (SB_P2P_TIMEOUT_MS)
 } g;
 
 inline bool multi_rank() { return g.comm != nullptr || g.hasXport; }
@@ -225,6 +227,7 @@ struct sb_halo {
   uint32_t *slot = nullptr; uint8_t* dest = nullptr; unsigned int* done = nullptr; // device arrays behind `push`
   int *dSrcRank = nullptr, *dRdispl = nullptr, *dRcount = nullptr, *err = nullptr;
   unsigned long long seq = 0;
+  char p2pReason[256] = "not set up";
 };
 
 struct sb_cg {
@@ -262,7 +265,7 @@ struct sb_cg {
 // Every sb_* function below is declared extern "C" by include/sbhip.h, which fixes
 // its linkage; the helpers in between stay C++.
 
-const char* sb_version(void) { return "sparsebench_amd sbhip 0.1 (gfx950)"; }
+const char* sb_version(void) { return "sparsebench_amd sbhip 0.2 (gfx950)"; }
 
 int sb_device_count(void)
 {

@@ -235,6 +235,7 @@ static void loop_body(sb_cg* s, int k)
     hw.flags = h->stage + 2 * (size_t)h->externalCount;
     hw.ext   = reinterpret_cast<const double*>(h->stage + (h->seq & 1ull) * (size_t)h->externalCount);
     hw.src = h->dSrcRank, hw.nsrc = h->indegree, hw.seq = h->seq, hw.err = h->err;
+    hw.stopw = &s->S->stop, hw.timeoutTicks = h->push.timeoutTicks;
     spmv_event(s);
     launch_spmv(s->A, s->p, s->Ap, s->partials, stop, 0, nullptr, &hw);
     spmv_event(s);
@@ -343,12 +344,15 @@ int sb_cg_finish(sb_cg* s)
   CgScalars h;
   HIP_CHECK(hipMemcpy(&h, s->S, sizeof h, hipMemcpyDeviceToHost));
   if (h.p2p_error)
-    SB_FATAL("rank %d: a peer's contribution to an in-kernel all-reduce did not arrive within 2 s "
-             "(SB_P2P=0 selects the RCCL all-reduce)", g.rank);
+    SB_FATAL("rank %d: a peer's contribution to an in-kernel all-reduce did not arrive within %lld ms "
+             "(SB_P2P_TIMEOUT_MS raises the bound, SB_P2P=0 selects the RCCL all-reduce)", g.rank,
+        g.p2pTimeoutTicks / P2P_TICKS_PER_MS);
   if (s->halo && s->halo->p2p) {
     int e = 0;
     HIP_CHECK(hipMemcpy(&e, s->halo->err, sizeof e, hipMemcpyDeviceToHost));
-    if (e) SB_FATAL("rank %d: a neighbour's halo block did not arrive within 2 s (SB_P2P_HALO=0 selects RCCL)", g.rank);
+    if (e)
+      SB_FATAL("rank %d: a neighbour's halo block did not arrive within %lld ms (SB_P2P_TIMEOUT_MS raises the bound, "
+               "SB_P2P_HALO=0 selects RCCL)", g.rank, g.p2pTimeoutTicks / P2P_TICKS_PER_MS);
   }
   if (s->timing) {
     for (double& v : s->region_ms) v = 0.0;

@@ -61,16 +61,24 @@ int sb_comm_p2p_handle(unsigned char* handle_out)
 {
   need_init();
   const char* env = getenv("SB_P2P");
-  if (env && atoi(env) == 0) return 0;
+  if (env && atoi(env) == 0) {
+    snprintf(g.p2pReason, sizeof g.p2pReason, "off: SB_P2P=0");
+    return 0;
+  }
   // test hook: SB_P2P_FAIL_RANK=r makes rank r behave as if its buffer could not be exported, to
   // exercise the collective fall-back decision (tests/test_gpu_multirank.py)
   const char* failRank = getenv("SB_P2P_FAIL_RANK");
-  if (failRank && atoi(failRank) == g.rank) return 0;
+  if (failRank && atoi(failRank) == g.rank) {
+    snprintf(g.p2pReason, sizeof g.p2pReason, "off: SB_P2P_FAIL_RANK=%d (test hook)", g.rank);
+    return 0;
+  }
   static_assert(sizeof(hipIpcMemHandle_t) <= SB_P2P_HANDLE_BYTES, "IPC handle size");
   if (!g.p2pBuf) {
     void* buf = nullptr; // fine-grained: coherent between GPUs while kernels are running
-    if (hipExtMallocWithFlags(&buf, 2 * P2P_MAX * sizeof(P2PSlot), hipDeviceMallocFinegrained) != hipSuccess) {
+    const hipError_t e = hipExtMallocWithFlags(&buf, 2 * P2P_MAX * sizeof(P2PSlot), hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
       (void)hipGetLastError();
+      snprintf(g.p2pReason, sizeof g.p2pReason, "off: fine-grained allocation failed on rank %d (%s)", g.rank, hipGetErrorName(e));
       return 0;
     }
     g.p2pBuf = (P2PSlot*)buf;
@@ -78,9 +86,11 @@ int sb_comm_p2p_handle(unsigned char* handle_out)
     HIP_CHECK(hipDeviceSynchronize());
   }
   hipIpcMemHandle_t h;
-  if (hipIpcGetMemHandle(&h, g.p2pBuf) != hipSuccess) {
+  const hipError_t eh = hipIpcGetMemHandle(&h, g.p2pBuf);
+  if (eh != hipSuccess) {
     (void)hipGetLastError();
     p2p_release();
+    snprintf(g.p2pReason, sizeof g.p2pReason, "off: hipIpcGetMemHandle failed on rank %d (%s)", g.rank, hipGetErrorName(eh));
     return 0;
   }
   memset(handle_out, 0, SB_P2P_HANDLE_BYTES);
@@ -92,24 +102,37 @@ int sb_comm_p2p_open(const unsigned char* all_handles)
 {
   need_init();
   if (!multi_rank()) return 0;
+  { // waits inside CG: generous, configurable; a late peer is not a dead peer
+    const char* t = getenv("SB_P2P_TIMEOUT_MS");
+    const long long ms = t && atoll(t) > 0 ? atoll(t) : 30000;
+    g.p2pTimeoutTicks = ms * P2P_TICKS_PER_MS;
+  }
+  char why[200] = "";
   int ok = all_handles != nullptr && g.p2pBuf != nullptr && g.size <= P2P_MAX;
+  if (!ok) snprintf(why, sizeof why, "rank %d: %s", g.rank, g.size > P2P_MAX ? "more than 16 ranks" : g.p2pReason);
   unsigned char zero[SB_P2P_HANDLE_BYTES] = { 0 };
   for (int r = 0; ok && r < g.size; r++) {
     const unsigned char* hb = all_handles + (size_t)r * SB_P2P_HANDLE_BYTES;
-    if (memcmp(hb, zero, SB_P2P_HANDLE_BYTES) == 0) ok = 0; // that rank has none
-    else if (r == g.rank) g.p2pPeer[r] = g.p2pBuf;
+    if (memcmp(hb, zero, SB_P2P_HANDLE_BYTES) == 0) {
+      ok = 0; // that rank has none
+      snprintf(why, sizeof why, "rank %d exported no buffer", r);
+    } else if (r == g.rank) g.p2pPeer[r] = g.p2pBuf;
     else {
       hipIpcMemHandle_t h;
       memcpy(&h, hb, sizeof h);
-      if (hipIpcOpenMemHandle(&g.p2pPeer[r], h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+      const hipError_t e = hipIpcOpenMemHandle(&g.p2pPeer[r], h, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) {
         (void)hipGetLastError();
         g.p2pPeer[r] = nullptr;
         ok = 0;
+        snprintf(why, sizeof why, "rank %d: hipIpcOpenMemHandle of rank %d's buffer failed (%s)", g.rank, r, hipGetErrorName(e));
       }
     }
   }
   // every rank must come to the same decision.  Round 1 (the established transport): did everybody
-  // map everybody?  Round 2: one in-kernel exchange, checked, and agreed on over the transport again.
+  // map everybody?  Round 2: SIX in-kernel exchanges (three per slot parity) with a value that changes
+  // every time -- a stale line of an earlier exchange of the same parity would be caught -- checked,
+  // and agreed on over the transport again.
   double* d = (double*)sb_malloc(4 * sizeof(double));
   auto agree = [&](int mine) {
     const double v = mine ? 1.0 : 0.0;
@@ -120,34 +143,74 @@ int sb_comm_p2p_open(const unsigned char* all_handles)
     return sum == (double)g.size;
   };
   bool on = agree(ok);
+  if (!on && ok) snprintf(why, sizeof why, "another rank could not export / map a buffer");
+  double p2pUs = 0.0;
   if (on) {
     P2PView view;
     memset(&view, 0, sizeof view);
     view.rank = g.rank, view.size = g.size;
+    view.timeoutTicks = 2000 * P2P_TICKS_PER_MS; // self-test: 2 s
     for (int r = 0; r < g.size; r++) view.peer[r] = (P2PSlot*)g.p2pPeer[r];
     HIP_CHECK(hipMalloc(&g.p2pView, sizeof view));
     HIP_CHECK(hipMemcpy(g.p2pView, &view, sizeof view, hipMemcpyHostToDevice));
     int* err = (int*)(d + 2);
-    HIP_CHECK(hipMemset(d, 0, 4 * sizeof(double)));
-    hipLaunchKernelGGL(p2p_selftest_k, dim3(1), dim3(64), 0, g.stream, (const P2PView*)g.p2pView, ++g.p2pSeq,
-        (double)(g.rank + 1), d + 1, err);
-    HIP_CHECK(hipGetLastError());
-    double got = 0.0;
-    int e      = 0;
-    sb_d2h(&got, d + 1, sizeof got);
-    sb_d2h(&e, err, sizeof e);
-    on = agree(!e && got == 0.5 * g.size * (g.size + 1));
+    int good = 1;
+    const int rounds = 6;
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    for (int it = 0; it < rounds && good; it++) {
+      HIP_CHECK(hipMemsetAsync(d, 0, 4 * sizeof(double), g.stream));
+      if (it == 2) HIP_CHECK(hipEventRecord(e0, g.stream));
+      const double mine = (double)(g.rank + 1) * (double)(it + 1) + 0.25 * it;
+      hipLaunchKernelGGL(p2p_selftest_k, dim3(1), dim3(64), 0, g.stream, (const P2PView*)g.p2pView, ++g.p2pSeq, mine,
+          d + 1, err);
+      HIP_CHECK(hipGetLastError());
+      if (it == rounds - 1) HIP_CHECK(hipEventRecord(e1, g.stream));
+      double got = 0.0;
+      int e      = 0;
+      sb_d2h(&got, d + 1, sizeof got);
+      sb_d2h(&e, err, sizeof e);
+      double want = 0.0; // the same pairwise tree the kernel uses
+      {
+        double v[P2P_MAX];
+        int n = g.size;
+        for (int r = 0; r < n; r++) v[r] = (double)(r + 1) * (double)(it + 1) + 0.25 * it;
+        while (n > 1) {
+          const int h = n >> 1;
+          for (int i = 0; i < h; i++) v[i] = v[2 * i] + v[2 * i + 1];
+          if (n & 1) v[h] = v[n - 1];
+          n = h + (n & 1);
+        }
+        want = v[0];
+      }
+      if (e || got != want) {
+        good = 0;
+        snprintf(why, sizeof why, "rank %d: self-test exchange %d %s", g.rank, it, e ? "timed out (2 s)" : "returned a wrong sum");
+      }
+    }
+    float ms = 0.f;
+    if (good && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) p2pUs = 1e3 * ms / (rounds - 2);
+    (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+    on = agree(good);
+    if (!on && good) snprintf(why, sizeof why, "the self-test failed on another rank");
+    if (on) { // production bound of the waits
+      view.timeoutTicks = g.p2pTimeoutTicks;
+      HIP_CHECK(hipMemcpy(g.p2pView, &view, sizeof view, hipMemcpyHostToDevice));
+    }
   }
   sb_free(d);
   if (!on) p2p_release();
   g.p2pOn = on;
+  if (on) snprintf(g.p2pReason, sizeof g.p2pReason, "on: %d ranks mapped, 6 self-test exchanges ok (~%.1f us each incl. launch + readback)", g.size, p2pUs);
+  else snprintf(g.p2pReason, sizeof g.p2pReason, "off: %s", why[0] ? why : "unknown");
   if (getenv("SB_PACK_REPORT") || getenv("SB_P2P_REPORT"))
-    fprintf(stderr, "sbhip comm: rank %d/%d in-kernel all-reduce over peer-mapped memory: %s\n", g.rank, g.size,
-        on ? "on" : "off (RCCL / transport all-reduce)");
+    fprintf(stderr, "sbhip comm: rank %d/%d in-kernel all-reduce over peer-mapped memory: %s\n", g.rank, g.size, g.p2pReason);
   return on ? 1 : 0;
 }
 
 int sb_comm_p2p_enabled(void) { return g.p2pOn ? 1 : 0; }
+const char* sb_comm_p2p_reason(void) { return g.p2pReason; }
 
 void sb_comm_finalize(void)
 {
@@ -273,9 +336,15 @@ static void halo_p2p_setup(sb_halo* h)
   const char* env = getenv("SB_P2P_HALO");
   // rides on the in-kernel all-reduce's decision (same memory model, same agreement); needs an
   // all-gather for the handles.  Every condition here is the same on every rank.
-  if (!g.p2pOn || g.size > P2P_MAX || !comm_can_allgather() || (env && atoi(env) == 0)) return;
+  if (!g.p2pOn || g.size > P2P_MAX || !comm_can_allgather() || (env && atoi(env) == 0)) {
+    snprintf(h->p2pReason, sizeof h->p2pReason, "off: %s", (env && atoi(env) == 0) ? "SB_P2P_HALO=0"
+        : !g.p2pOn ? "the in-kernel all-reduce is off (same memory model)" : g.size > P2P_MAX ? "more than 16 ranks"
+        : "the transport has no all-gather for the handles");
+    return;
+  }
   const int P = g.size, E = h->externalCount;
   int ok      = 1;
+  char why[200] = "";
   // 1. own staging area + flags, exported
   struct Info {
     unsigned char handle[SB_P2P_HANDLE_BYTES];
@@ -291,6 +360,7 @@ static void halo_p2p_setup(sb_halo* h)
   if (hipExtMallocWithFlags(&buf, words * sizeof(unsigned long long), hipDeviceMallocFinegrained) != hipSuccess) {
     (void)hipGetLastError();
     ok = 0;
+    snprintf(why, sizeof why, "rank %d: fine-grained allocation of the staging area failed", g.rank);
   } else {
     h->stage = (unsigned long long*)buf;
     HIP_CHECK(hipMemset(h->stage, 0, words * sizeof(unsigned long long)));
@@ -299,6 +369,7 @@ static void halo_p2p_setup(sb_halo* h)
     if (hipIpcGetMemHandle(&ih, h->stage) != hipSuccess) {
       (void)hipGetLastError();
       ok = 0;
+      snprintf(why, sizeof why, "rank %d: hipIpcGetMemHandle of the staging area failed", g.rank);
     } else memcpy(mine.handle, &ih, sizeof ih);
   }
   comm_allgather(&mine, (int)sizeof mine, all);
@@ -311,6 +382,7 @@ static void halo_p2p_setup(sb_halo* h)
     const int d = h->destinations[i];
     if (i >= P2P_MAX || memcmp(all[d].handle, zero, sizeof zero) == 0 || all[d].rdisplOf[g.rank] < 0) {
       ok = 0;
+      snprintf(why, sizeof why, "rank %d: destination %d exported no staging area / does not expect this rank", g.rank, d);
       break;
     }
     hipIpcMemHandle_t ih;
@@ -319,6 +391,7 @@ static void halo_p2p_setup(sb_halo* h)
       (void)hipGetLastError();
       h->peerStage[i] = nullptr;
       ok = 0;
+      snprintf(why, sizeof why, "rank %d: hipIpcOpenMemHandle of rank %d's staging area failed", g.rank, d);
       break;
     }
     h->push.stage[i] = (unsigned long long*)h->peerStage[i];
@@ -340,6 +413,7 @@ static void halo_p2p_setup(sb_halo* h)
     return sum == (double)P;
   };
   bool on = agree(ok);
+  if (!on && ok) snprintf(why, sizeof why, "another rank could not export / map a staging area");
   if (on) {
     h->slot = (uint32_t*)upload(slot.data(), slot.size() * sizeof(uint32_t));
     h->dest = (uint8_t*)upload(dest.data(), dest.size());
@@ -352,32 +426,46 @@ static void halo_p2p_setup(sb_halo* h)
     h->dRcount  = (int*)upload(h->recvCounts.data(), h->recvCounts.size() * sizeof(int));
     h->push.n = (uint32_t)h->totalSend, h->push.ndest = h->outdegree, h->push.rank = g.rank;
     h->push.packIdx = h->packIdx, h->push.slot = h->slot, h->push.dest = h->dest, h->push.done = h->done;
-    // self-test: every rank sends (rank + 1) in all its slots; the block from source s must read s + 1
+    h->push.timeoutTicks = 2000 * P2P_TICKS_PER_MS; // self-test: 2 s
+    // self-test: SIX exchanges (three per parity of the alternating staging areas); in exchange `it` every rank
+    // sends value(rank, it) in all its slots, so a block that still holds an earlier exchange's data is caught
     const size_t nvec = (size_t)h->nr + (size_t)E + 1;
     double* v         = (double*)sb_malloc(nvec * sizeof(double));
-    std::vector<double> host(nvec, (double)(g.rank + 1));
-    sb_h2d(v, host.data(), nvec * sizeof(double));
-    h->p2p = true;
-    halo_exchange(h, v, nullptr, g.stream, true);
-    sb_d2h(host.data(), v, nvec * sizeof(double));
-    int e = 0;
-    sb_d2h(&e, h->err, sizeof e);
-    int good = !e;
-    for (int j = 0; good && j < h->indegree; j++)
-      for (int i = 0; i < h->recvCounts[j]; i++)
-        if (host[(size_t)h->nr + h->rdispls[j] + i] != (double)(h->sources[j] + 1)) {
-          good = 0;
-          break;
-        }
+    std::vector<double> host(nvec);
+    auto value = [](int rank, int it) { return (double)(rank + 1) + 1000.0 * (double)it; };
+    h->p2p   = true;
+    int good = 1;
+    for (int it = 0; it < 6 && good; it++) {
+      std::fill(host.begin(), host.end(), value(g.rank, it));
+      sb_h2d(v, host.data(), nvec * sizeof(double));
+      halo_exchange(h, v, nullptr, g.stream, true);
+      sb_d2h(host.data(), v, nvec * sizeof(double));
+      int e = 0;
+      sb_d2h(&e, h->err, sizeof e);
+      if (e) {
+        good = 0;
+        snprintf(why, sizeof why, "rank %d: self-test exchange %d timed out (2 s)", g.rank, it);
+      }
+      for (int j = 0; good && j < h->indegree; j++)
+        for (int i = 0; i < h->recvCounts[j]; i++)
+          if (host[(size_t)h->nr + h->rdispls[j] + i] != value(h->sources[j], it)) {
+            good = 0;
+            snprintf(why, sizeof why, "rank %d: self-test exchange %d delivered wrong data from rank %d", g.rank, it, h->sources[j]);
+            break;
+          }
+    }
     sb_free(v);
     on = agree(good);
+    if (!on && good) snprintf(why, sizeof why, "the self-test failed on another rank");
+    h->push.timeoutTicks = g.p2pTimeoutTicks;
   }
   sb_free(dflag);
   if (!on) halo_p2p_release(h);
   h->p2p = on;
+  if (on) snprintf(h->p2pReason, sizeof h->p2pReason, "on: %d destinations mapped, 6 self-test exchanges ok", h->outdegree);
+  else snprintf(h->p2pReason, sizeof h->p2pReason, "off: %s", why[0] ? why : "unknown");
   if (getenv("SB_PACK_REPORT") || getenv("SB_P2P_REPORT"))
-    fprintf(stderr, "sbhip comm: rank %d/%d halo exchange over peer-mapped memory: %s\n", g.rank, g.size,
-        on ? "on" : "off (RCCL / transport send-recv)");
+    fprintf(stderr, "sbhip comm: rank %d/%d halo exchange over peer-mapped memory: %s\n", g.rank, g.size, h->p2pReason);
 }
 
 sb_halo* sb_halo_create(uint32_t nr, int outdegree, const int* destinations, const int* sendCounts,
@@ -422,6 +510,7 @@ sb_halo* sb_halo_create(uint32_t nr, int outdegree, const int* destinations, con
 }
 
 int sb_halo_p2p_enabled(const sb_halo* h) { return h && h->p2p ? 1 : 0; }
+const char* sb_halo_p2p_reason(const sb_halo* h) { return h ? h->p2pReason : "no halo plan (one rank)"; }
 
 void sb_halo_free(sb_halo* h)
 {
@@ -444,7 +533,8 @@ static void halo_exchange(sb_halo* h, double* x, const int* stop, hipStream_t st
       hipLaunchKernelGGL(halo_push_k, dim3(stream_grid(h->totalSend, 256)), dim3(256), 0, stream, h->push, x, seq, stop);
     if (h->indegree && !pushOnly)
       hipLaunchKernelGGL(halo_pull_k, dim3(h->indegree), dim3(256), 0, stream, h->dSrcRank, h->dRdispl, h->dRcount,
-          h->stage, h->stage + 2 * (size_t)h->externalCount, (uint32_t)h->externalCount, x + h->nr, seq, h->err, stop);
+          h->stage, h->stage + 2 * (size_t)h->externalCount, (uint32_t)h->externalCount, x + h->nr, seq, h->err,
+          const_cast<int*>(stop), h->push.timeoutTicks);
     HIP_CHECK(hipGetLastError());
     return;
   }

@@ -583,6 +583,20 @@ static void build_crs_mirror(sb_matrix* m, const uint32_t* rowPtr, const uint32_
 {
   const char* env = getenv("SB_PACK");
   if ((env ? atoi(env) : 5) < 4 || m->nr == 0 || m->nnz == 0) return;
+  { // the pattern levels need the value dictionary (<= 256 distinct bit patterns): decide that first, cheaply
+    std::vector<unsigned long long> seen;
+    unsigned long long last = ~0ull;
+    for (uint32_t k = 0; k < m->nnz; k++) {
+      unsigned long long b;
+      memcpy(&b, val + k, 8);
+      if (b == last) continue;
+      last = b;
+      if (std::find(seen.begin(), seen.end(), b) == seen.end()) {
+        seen.push_back(b);
+        if (seen.size() > 255) return; // (+0.0 for padding takes one entry)
+      }
+    }
+  }
   const uint32_t nr = m->nr, nChunks = (nr + 63) / 64;
   std::vector<uint32_t> chunkLens(nChunks, 0), chunkPtr(nChunks + 1, 0);
   for (uint32_t i = 0; i < nr; i++) chunkLens[i / 64] = std::max(chunkLens[i / 64], rowPtr[i + 1] - rowPtr[i]);

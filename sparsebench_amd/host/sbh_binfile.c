@@ -136,6 +136,10 @@ void sbh_init_matrix(Comm* c, Parameter* p, GMatrix* m)
     matrixGenerate(m, p, c->rank, c->size, false);
     return;
   }
+  if (strcmp(p->filename, "irregular") == 0) { /* Flan_1565 stand-in (sbh_irregular.c), enters like a file */
+    sbh_matrix_generate_irregular(m, p, c->rank, c->size);
+    return;
+  }
   if (strcmp(p->filename, "generate7P") == 0) {
     matrixGenerate(m, p, c->rank, c->size, true);
     return;

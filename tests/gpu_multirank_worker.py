@@ -63,11 +63,21 @@ def main():
         live = ref / ref[0] >= 1e-20
         assert (np.abs(rr - ref) / ref)[live].max() <= 1e-12  # north_star tolerance vs the MPI reference
     dist.barrier()
-    p2p = L.sb_comm_p2p_enabled()
+    # the data plane every rank REALLY used (both set-ups are collective decisions: all ranks agree)
+    p2p, halo_p2p = L.sb_comm_p2p_enabled(), L.sb_halo_p2p_enabled(prob.halo)
+    flags = torch.tensor([p2p, halo_p2p], dtype=torch.int32)
+    lo, hi = flags.clone(), flags.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    assert torch.equal(lo, hi), "ranks disagree on the data plane: %r vs %r" % (lo.tolist(), hi.tolist())
+    why, why_halo = L.sb_comm_p2p_reason().decode(), L.sb_halo_p2p_reason(prob.halo).decode()
     prob.free()
     L.sb_comm_finalize()
     if rank == 0:
         print("P2P_ENABLED", p2p, flush=True)
+        print("HALO_P2P_ENABLED", halo_p2p, flush=True)
+        print("P2P_REASON", why, flush=True)
+        print("HALO_P2P_REASON", why_halo, flush=True)
         print("GPU_MULTIRANK_OK", fmt, Cc, sigma, n, size, flush=True)
     dist.destroy_process_group()
 

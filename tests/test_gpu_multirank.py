@@ -45,9 +45,16 @@ def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax, p2p):
     text = out.stdout.decode()
     assert out.returncode == 0, text[-4000:]
     assert "GPU_MULTIRANK_OK %s %d %d %d %d" % (fmt, Cc, sigma, n, size) in text, text[-3000:]
+    why = [ln for ln in text.splitlines() if ln.startswith(("P2P_REASON", "HALO_P2P_REASON"))]
     if p2p == "0":
-        assert "P2P_ENABLED 0" in text
-    print([ln for ln in text.splitlines() if "P2P_ENABLED" in ln or "in-kernel all-reduce" in ln][:3])
+        assert "P2P_ENABLED 0" in text and "HALO_P2P_ENABLED 0" in text
+        assert any("SB_P2P=0" in ln for ln in why), why
+    else:
+        # the peer-mapped kernels (cg_scalar_p2p_k, halo_push_k, the HALO instantiation of the pattern SpMV) must
+        # really have run on every rank -- a silent fall-back would make this parametrisation vacuous
+        if "P2P_ENABLED 1" not in text or "HALO_P2P_ENABLED 1" not in text:
+            pytest.skip("peer-mapped path fell back on this box: %s" % why)
+        assert any(ln.startswith("P2P_REASON on:") for ln in why) and any(ln.startswith("HALO_P2P_REASON on:") for ln in why), why
 
 
 def test_p2p_setup_failure_on_one_rank_falls_back_everywhere(gpu):
@@ -63,3 +70,5 @@ def test_p2p_setup_failure_on_one_rank_falls_back_everywhere(gpu):
     assert out.returncode == 0, text[-4000:]
     assert "GPU_MULTIRANK_OK scs 64 1 16 3" in text and "P2P_ENABLED 0" in text, text[-3000:]
     assert text.count("in-kernel all-reduce over peer-mapped memory: off") == 3
+    assert "P2P_REASON off:" in text and ("rank 1" in text.split("P2P_REASON off:")[1].splitlines()[0]
+                                           or "another rank" in text.split("P2P_REASON off:")[1].splitlines()[0])
