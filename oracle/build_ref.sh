@@ -80,12 +80,15 @@ fi
 # The reference's OWN driver, unchanged, on top of the MI355X drop-in: src/main.c compiled against the
 # forwarding headers (include/sparsebench/compat) and linked with libsparsebench_<fmt>.so -- no reference
 # object besides main.o.  Lets the GPU box RUN "main.c drives it" (tests/test_gpu_dropin.py).
+# (main.c is compiled from a scratch copy in $TMP: `#include "comm.h"` looks in the including file's own directory
+#  first, so compiled in place it would pick the reference's headers, not the forwarding ones)
 REPO=$(cd "$HERE/.." && pwd)
 if [ -f "$REPO/sparsebench_amd/lib/libsparsebench_crs.so" ]; then
+  cp "$S/main.c" "$TMP/main.c"
   for F in CRS SCS; do
     f=$(echo $F | tr A-Z a-z)
     gcc -std=gnu11 -O1 -w -D$F -DPRECISION=2 -DUINT_TYPE=1 -DARRAY_ALIGNMENT=64 \
-      -I"$REPO/include/sparsebench/compat" -I"$REPO/include" "$S/main.c" -o "$OUT/refmain_${F}_hip" \
+      -I"$REPO/include/sparsebench/compat" -I"$REPO/include" "$TMP/main.c" -o "$OUT/refmain_${F}_hip" \
       -L"$REPO/sparsebench_amd/lib" -lsparsebench_$f -lsparsebench_host -lsbhip \
       -Wl,-rpath,'$ORIGIN/../../sparsebench_amd/lib' -lm || echo "build_ref: refmain_$F failed (non-fatal)" >&2
   done

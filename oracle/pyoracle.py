@@ -86,6 +86,8 @@ def lib():
     L.orc_ddot_seq.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
     L.orc_ddot_tree.restype = C.c_double
     L.orc_ddot_tree.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
+    L.orc_ddot_exact.restype = C.c_double
+    L.orc_ddot_exact.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
     L.orc_ddot_partials.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_reduce_final.restype = C.c_double
     L.orc_reduce_final.argtypes = [C.c_uint32, C.c_void_p]
@@ -256,6 +258,10 @@ def ddot_tree(x, y):
     return lib().orc_ddot_tree(len(x), _p(x), _p(y))
 
 
+def ddot_exact(x, y):
+    return lib().orc_ddot_exact(len(x), _p(x), _p(y))
+
+
 def ddot_partials(x, y):
     q = np.empty((len(x) + 255) // 256, dtype=np.float64)
     lib().orc_ddot_partials(len(x), _p(x), _p(y), _p(q))
@@ -281,7 +287,7 @@ def cg(locals_, plans=None, fmt="crs", Cc=64, sigma=1, itermax=150, eps=0.0, dot
     xo = (_f64p * Pn)() if want_x else None
     k = lib().orc_cg(arr, plans.ptr if plans is not None else None, Pn,
                      0 if fmt == "crs" else 1, Cc, sigma, itermax, eps,
-                     0 if dot == "seq" else 1, 0 if rank_sum == "order" else 1, _p(rr),
+                     {"seq": 0, "tree": 1, "exact": 2}[dot], 0 if rank_sum == "order" else 1, _p(rr),
                      C.byref(nrr), _p(pap), C.byref(npap), xo, C.byref(err))
     out = {"k": k, "rr": rr[:nrr.value].copy(), "pAp": pap[:npap.value].copy(),
            "max_err": err.value}

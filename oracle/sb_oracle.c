@@ -580,6 +580,27 @@ double orc_ddot_seq(uint32_t n, const double* x, const double* y)
   return sum;
 }
 
+/* "Exact" dot: Ogita-Rump-Oishi Dot2 -- every product split error-free (TwoProduct through fma), every
+ * addition error-free (TwoSum), the error terms accumulated separately and added at the end: the result
+ * is as good as a sum carried in twice the working precision and then rounded once.  For r.r (condition
+ * number 1) and p.Ap (SPD: no cancellation to speak of) that IS the correctly rounded value up to a
+ * relative 2^-53 * (1 + n * 2^-53 * cond): the yardstick both the reference's sequential sum and the GPU's
+ * tree sum are measured against (tests/golden/cg_hist_exact.json, tests/test_gpu_cg.py).  One thread. */
+double orc_ddot_exact(uint32_t n, const double* x, const double* y)
+{
+  double s = 0.0, c = 0.0;
+  for (uint32_t i = 0; i < n; i++) {
+    const double p  = x[i] * y[i];
+    const double pe = fma(x[i], y[i], -p); /* x*y = p + pe exactly */
+    const double t  = s + p;
+    const double z  = t - s;
+    const double se = (s - (t - z)) + (p - z); /* s + p = t + se exactly */
+    s = t;
+    c += se + pe;
+  }
+  return s + c;
+}
+
 /* Canonical reduction order of the HIP kernels (DESIGN.md "dot order").
  * Level 0: every aligned group of 64 consecutive elements is reduced by an xor
  * butterfly with offsets 1,2,4,8,16,32 (what 64 lanes do with shuffles).
@@ -748,8 +769,9 @@ int orc_cg(orc_gmatrix** L, const orc_plan* plans, int P, int fmt, uint32_t C, u
 #define DOT(A, B, OUT)                                                              \
   do {                                                                              \
     for (int q_ = 0; q_ < P; q_++)                                                  \
-      loc[q_] = dot_mode ? tree_dot_in_storage_order(&st[q_], st[q_].A, st[q_].B)   \
-                         : orc_ddot_seq(st[q_].g->nr, st[q_].A, st[q_].B);          \
+      loc[q_] = dot_mode == 2 ? orc_ddot_exact(st[q_].g->nr, st[q_].A, st[q_].B)    \
+                : dot_mode    ? tree_dot_in_storage_order(&st[q_], st[q_].A, st[q_].B) \
+                              : orc_ddot_seq(st[q_].g->nr, st[q_].A, st[q_].B);     \
     (OUT) = reduce_ranks(loc, P, rank_sum);                                         \
   } while (0)
 

@@ -88,6 +88,8 @@ void orc_waxpby(uint32_t n, double alpha, const double* x, double beta,
                 const double* y, double* w);
 double orc_ddot_seq(uint32_t n, const double* x, const double* y);
 double orc_ddot_tree(uint32_t n, const double* x, const double* y);
+/* Dot2 (twice the working precision, rounded once): the "exactly rounded" yardstick; orc_cg dot_mode 2 */
+double orc_ddot_exact(uint32_t n, const double* x, const double* y);
 /* canonical order pieces, exposed so tests can check each GPU stage */
 void orc_ddot_partials(uint32_t n, const double* x, const double* y, double* partials);
 double orc_reduce_final(uint32_t m, const double* partials);

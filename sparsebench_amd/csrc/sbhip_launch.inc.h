@@ -31,10 +31,22 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
   if (m->fmt == 0 && spmv_uses_patterns(m)) {
     launch_pat(m->mirror, true, x, y, dotPartials, stop, part, stream ? stream : g.stream, halo);
   } else if (m->fmt == 0) {
-    if (dot) SB_FATAL("fused dot needs the pattern kernel (SCS C=64, or CRS through its mirror)");
     const uint32_t per = (m->nRowBlocks + 7) / 8;
-    hipLaunchKernelGGL(spmv_crs_stream, dim3(per * 8), dim3(CRS_THREADS), 0, g.stream, m->rowBlocks,
-        m->rowPtr, m->colInd, m->val, x, y, m->nRowBlocks, per, stop);
+    static const int crsBatch = getenv("SB_CRS_BATCH") ? atoi(getenv("SB_CRS_BATCH")) : 4; // 4: 240 us, 8: 253 us (irregular, 94 M nnz)
+#define CRS_LAUNCH(DO, BA)                                                                                              \
+  hipLaunchKernelGGL((spmv_crs_rows<DO, BA>), dim3(per * 8), dim3(CRS_THREADS), 0, g.stream, m->rowBlocks, m->rowPtr, \
+      m->colInd, m->val, x, y, m->nr, m->nRowBlocks, per, dotPartials, stop)
+    if (crsBatch == 4) {
+      if (dot) CRS_LAUNCH(true, 4);
+      else CRS_LAUNCH(false, 4);
+    } else if (crsBatch == 2) {
+      if (dot) CRS_LAUNCH(true, 2);
+      else CRS_LAUNCH(false, 2);
+    } else {
+      if (dot) CRS_LAUNCH(true, 8);
+      else CRS_LAUNCH(false, 8);
+    }
+#undef CRS_LAUNCH
   } else if (m->C == 64) {
     if (g_scs_unroll < 0) {
       const char* u = getenv("SB_SCS_UNROLL");

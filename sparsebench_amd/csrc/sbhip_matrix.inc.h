@@ -23,22 +23,41 @@ sb_matrix* sb_crs_upload(uint32_t nr, uint32_t nc, const uint32_t* rowPtr, const
     if (rowPtr[i + 1] < rowPtr[i]) SB_FATAL("CRS rowPtr not monotone at row %u", i);
   for (uint32_t k = 0; k < m->nnz; k++)
     if (colInd[k] >= nc) SB_FATAL("CRS colInd[%u]=%u out of range (nc=%u)", k, colInd[k], nc);
-  // Row blocks: as many rows as fit CRS_TILE nonzeros and CRS_THREADS rows; a row
-  // longer than the tile gets a block of its own.
+  if ((uint64_t)m->nnz + 2u * CRS_TILE >= 0xFFFFFFFFull) SB_FATAL("CRS: %u nonzeros leave no room for 32-bit tile arithmetic", m->nnz);
+  // Work decomposition of spmv_crs_rows: a workgroup takes whole groups of 64 rows (the level-0 groups of
+  // the canonical dot) holding about `target` nonzeros -- several tiles, so that its software pipeline has
+  // something to overlap -- but never so many that the grid cannot fill the device (>= ~20 workgroups per CU
+  // where the matrix is big enough).
+  const uint32_t nGroups = (nr + 63u) / 64u;
+  const uint64_t wantBlocks = (uint64_t)g.prop.multiProcessorCount * 20u;
+  uint64_t target = wantBlocks ? (uint64_t)m->nnz / wantBlocks : (uint64_t)m->nnz;
+  target = std::min<uint64_t>(std::max<uint64_t>(target, CRS_TILE), 8u * CRS_TILE);
+  {
+    const char* e = getenv("SB_CRS_BLOCK_TILES");
+    if (e && atoi(e) > 0) target = (uint64_t)atoi(e) * CRS_TILE;
+  }
   std::vector<uint32_t> rb;
   rb.push_back(0);
-  uint32_t r = 0;
-  while (r < nr) {
-    uint32_t start = r, base = rowPtr[r];
-    while (r < nr && r - start < (uint32_t)CRS_THREADS && rowPtr[r + 1] - base <= (uint32_t)CRS_TILE) r++;
-    if (r == start) r++; // single oversize row
-    rb.push_back(r);
+  uint32_t gi = 0;
+  while (gi < nGroups) {
+    const uint32_t start = gi;
+    const uint64_t base  = rowPtr[(size_t)gi * 64];
+    do gi++;
+    while (gi < nGroups && (uint64_t)rowPtr[std::min<size_t>((size_t)(gi + 1) * 64, nr)] - base <= target && gi - start < (uint32_t)CRS_MAX_GROUPS);
+    rb.push_back(gi);
   }
   m->nRowBlocks = (uint32_t)rb.size() - 1;
   m->rowBlocks  = (uint32_t*)upload(rb.data(), rb.size() * sizeof(uint32_t));
   m->rowPtr     = (uint32_t*)upload(rowPtr, ((size_t)nr + 1) * sizeof(uint32_t));
-  m->colInd     = (uint32_t*)upload(colInd, (size_t)m->nnz * sizeof(uint32_t));
-  m->val        = (double*)upload(val, (size_t)m->nnz * sizeof(double));
+  // 64 zeroed elements of slack: the kernel's clamped stream loads of an all-empty tail block read element nnz
+  HIP_CHECK(hipMalloc(&m->colInd, ((size_t)m->nnz + 64) * sizeof(uint32_t)));
+  HIP_CHECK(hipMalloc(&m->val, ((size_t)m->nnz + 64) * sizeof(double)));
+  HIP_CHECK(hipMemset(m->colInd + m->nnz, 0, 64 * sizeof(uint32_t)));
+  HIP_CHECK(hipMemset(m->val + m->nnz, 0, 64 * sizeof(double)));
+  if (m->nnz) {
+    HIP_CHECK(hipMemcpy(m->colInd, colInd, (size_t)m->nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(m->val, val, (size_t)m->nnz * sizeof(double), hipMemcpyHostToDevice));
+  }
   build_crs_mirror(m, rowPtr, colInd, val);
   return m;
 }
@@ -131,9 +150,13 @@ static void build_packed(sb_matrix* m, const double* hostVal, const uint32_t* ol
   HIP_CHECK(hipStreamSynchronize(g.stream));
   if (dbits) HIP_CHECK(hipFree(dbits));
   m->packLevel   = m->nDict ? 2 : 1;
-  m->usePacked   = 1;
   m->packedBytes = (double)units * 512.0 + (m->nDict ? (double)grp * 256.0 : 8.0 * m->nElems) +
                    16.0 * m->nChunks;
+  // default kernel: the packed stream only where it really is smaller.  A matrix whose chunks span more than
+  // 65535 columns (far couplings: the irregular stand-in) keeps 32-bit indices and fp64 values -- the same
+  // bytes regrouped -- and the reference-layout kernel is the faster one there (260 vs 327 us at 94 M
+  // nonzeros).  sb_matrix_use_packed(m, 1) selects it regardless.
+  m->usePacked = m->packedBytes <= 0.9 * (12.0 * m->nElems) ? 1 : 0;
 }
 
 // Level 3 of the compressed mirror: per tile (4 chunks = one workgroup) the contiguous

@@ -50,6 +50,9 @@ int solveCG(Comm* comm, Parameter* param, Matrix* m)
 #error "compile with -DCRS or -DSCS"
 #endif
 
+void sbh_print_banner(Comm* c, const char* fmt);
+void commPrintBanner(Comm* c) { sbh_print_banner(c, FMT); } /* src/comm.c:185-250: names the build's format */
+
 void spMVM(Matrix* m, const CG_FLOAT* restrict x, CG_FLOAT* restrict y)
 {
   sbh_spmv(m->dev, m->nr, m->nc, x, y);

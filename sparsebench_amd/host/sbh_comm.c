@@ -123,18 +123,16 @@ void commAbort(Comm* c, char* msg)
   exit(EXIT_SUCCESS);
 }
 
-void commPrintBanner(Comm* c)
+/* src/comm.c:185-250: banner; the format name comes from the per-format library (dropin.c), as the reference's
+ * comes from its -DCRS|-DSCS build */
+void sbh_print_banner(Comm* c, const char* fmt)
 {
   if (!commIsMaster(c)) return;
   printf(HLINE);
   printf("SparseBench CG hot path -- MI355X HIP build (%s)\n", sb_version());
   printf("Device: %s, %d CUs\n", sb_device_name(), sb_num_cus());
-#ifdef FMT
-  printf("Using %s matrix format, %s precision floats and integer type %s\n", FMT, PRECISION_STRING,
-      UINT_STRING);
-#else
-  printf("Using %s precision floats and integer type %s\n", PRECISION_STRING, UINT_STRING);
-#endif
+  if (fmt) printf("Using %s matrix format, %s precision floats and integer type %s\n", fmt, PRECISION_STRING, UINT_STRING);
+  else printf("Using %s precision floats and integer type %s\n", PRECISION_STRING, UINT_STRING);
   if (c->size > 1) printf("RCCL parallel using %d ranks (one per GPU)\n", c->size);
   else printf("Running with only one process!\n");
   printf(HLINE);

@@ -83,8 +83,14 @@ def test_reference_main_compiles_unchanged_and_links_the_dropin(fmt, tmp_path):
     it".  (It is compiled from where it lies; nothing is copied into the repo.  oracle/build_ref.sh
     builds the same executables into oracle/_ref/ so the GPU box can RUN them: test_gpu_dropin.py.)"""
     exe = str(tmp_path / ("refmain_%s" % fmt))
+    # a scratch copy: `#include "comm.h"` searches the including file's own directory first, so compiled where it
+    # lies the driver would see the reference's headers (and its 16-byte serial Comm) instead of the forwarding ones
+    src = str(tmp_path / "main.c")
+    import shutil
+    shutil.copy(REF_MAIN, src)
+    assert open(src, "rb").read() == open(REF_MAIN, "rb").read()  # not one byte changed
     cmd = ["gcc", "-std=gnu11", "-O1", "-w", "-D" + fmt, "-DPRECISION=2", "-DUINT_TYPE=1", "-DARRAY_ALIGNMENT=64",
-           "-I" + COMPAT, "-I" + os.path.join(ROOT, "include"), REF_MAIN, "-o", exe, "-L" + LIB,
+           "-I" + COMPAT, "-I" + os.path.join(ROOT, "include"), src, "-o", exe, "-L" + LIB,
            "-lsparsebench_%s" % fmt.lower(), "-lsparsebench_host", "-lsbhip", "-Wl,-rpath," + LIB, "-lm"]
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert out.returncode == 0, out.stdout.decode()
@@ -92,6 +98,10 @@ def test_reference_main_compiles_unchanged_and_links_the_dropin(fmt, tmp_path):
     nm = subprocess.run(["nm", "-u", exe], stdout=subprocess.PIPE).stdout.decode()
     for sym in ("solveCG", "convertMatrix", "spMVM", "commPartition", "changeFileEnding", "matrixBinWrite"):
         assert re.search(r"\bU %s\b" % sym, nm), sym
+    # the driver was built against OUR struct layouts (the reference's serial Comm is 16 bytes, ours carries the plan)
+    deps = subprocess.run(["gcc", "-std=gnu11", "-w", "-D" + fmt, "-I" + COMPAT, "-I" + os.path.join(ROOT, "include"), "-M", src],
+                          stdout=subprocess.PIPE).stdout.decode()
+    assert "sparsebench/compat/comm.h" in deps and "/root/reference/src/comm.h" not in deps
     ldd = subprocess.run(["ldd", exe], stdout=subprocess.PIPE).stdout.decode()
     assert "libsparsebench_%s.so" % fmt.lower() in ldd and "libsbhip.so" in ldd and "sbref" not in ldd
 

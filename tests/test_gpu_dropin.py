@@ -140,3 +140,36 @@ def test_reference_main_c_drives_the_hip_path(gpu, fmt, golden_1rank, tmp_path):
     subprocess.run([exe, "-c", str(mtx)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
     golden = open(os.path.join(REFDATA, "matrix_band_klein.bmx"), "rb").read()
     assert open(tmp_path / "matrix_band_klein.bmx", "rb").read() == golden
+
+
+@pytest.mark.parametrize("fmt", ["CRS", "SCS"])
+@pytest.mark.parametrize("inp", ["hpcg32", "band_klein", "irregular"])
+def test_run_benchmarks_executable(gpu, fmt, inp):
+    """runBenchmarks-<FMT>-HIP (benchmarks/runBenchmarks.c:1-5 is an empty stub with the TODO "bench ddot, waxpby,
+    spMVM"): exit 0, the three kernel rows, and the spMVM byte figure equal to sb_matrix_spmv_bytes of the same
+    matrix (the algorithmic bytes of SURVEY 8d)."""
+    from sparsebench_amd import hostapi
+    exe = os.path.join(BIN, "runBenchmarks-%s-HIP" % fmt)
+    if inp == "hpcg32":
+        args, pa = ["-x", "32", "-y", "32", "-z", "32"], ("generate", 32, 32, 32)
+    elif inp == "irregular":
+        args, pa = ["-m", "irregular", "-x", "12", "-y", "12", "-z", "12"], ("irregular", 12, 12, 12)
+    else:
+        klein = os.path.join(REFDATA, "matrix_band_klein.mtx")
+        args, pa = ["-m", klein], (klein, 1, 1, 1)
+    extra = ["-C", "64", "-s", "32"] if fmt == "SCS" else []
+    out = subprocess.run([exe] + args + ["-i", "20"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    txt = out.stdout.decode()
+    rows = {m.group(1): [float(v) for v in m.group(2).split()] for m in re.finditer(r"^(spMVM|waxpby|ddot)\s+([0-9][0-9. ]*)$", txt, re.M)}
+    assert set(rows) == {"spMVM", "waxpby", "ddot"}, txt
+    for name, (us, gbs_alg, gbs_ref, gflops) in rows.items():
+        assert us > 0 and gbs_alg > 0 and gflops > 0, (name, us)
+    prob = hostapi.Problem(pa[0], pa[1], pa[2], pa[3], fmt=fmt.lower(), Cc=64, sigma=32)
+    alg = prob.spmv_bytes()
+    m = re.search(r"spMVM moves ([0-9.]+) MB per launch \(reference layout: ([0-9.]+) MB", txt)
+    assert m and abs(float(m.group(2)) - alg / 1e6) <= 0.051, (m and m.group(0), alg)
+    us, gbs_alg = rows["spMVM"][0], rows["spMVM"][1]
+    assert abs(gbs_alg - alg / (us * 1e-6) / 1e9) <= 0.02 * gbs_alg + 0.1  # rate = those bytes / the printed time
+    assert re.search(r"rows %d  stored nonzeros %d " % (prob.nr, prob.nnzTrue), txt), txt
+    prob.free()

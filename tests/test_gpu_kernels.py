@@ -54,7 +54,7 @@ def gpu_spmv(L, m, x, nr):
     elif L.sb_matrix_pack_level(m) > 0:
         best = L.sb_matrix_packed_mode(m)
         # (matrices of at most one round of resident workgroups default to mode 2 even when mode 3 exists)
-        assert best in ((2, 3) if L.sb_matrix_pattern_classes(m) else (2,) if L.sb_matrix_lds_window(m) else (1,))
+        assert best in ((2, 3) if L.sb_matrix_pattern_classes(m) else (2,) if L.sb_matrix_lds_window(m) else (0, 1))  # 1 only where the packed stream is smaller
         # reference stream / packed + cache gathers / packed + LDS window / pattern codes + LDS window
         for mode in (0, 1, 2, 3):
             L.sb_matrix_use_packed(m, mode)

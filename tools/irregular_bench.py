@@ -16,7 +16,7 @@ from sparsebench_amd.capi import DeviceVector  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 80
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-sigmas = [int(s) for s in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 4096, 65536]
+sigmas = [int(s) for s in sys.argv[3].split(",") if s.strip().isdigit()] if len(sys.argv) > 3 else [1, 256, 4096]
 L = capi.init(0)
 rows = []
 
