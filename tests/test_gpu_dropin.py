@@ -164,7 +164,7 @@ def test_run_benchmarks_executable(gpu, fmt, inp):
     rows = {m.group(1): [float(v) for v in m.group(2).split()] for m in re.finditer(r"^(spMVM|waxpby|ddot)\s+([0-9][0-9. ]*)$", txt, re.M)}
     assert set(rows) == {"spMVM", "waxpby", "ddot"}, txt
     for name, (us, gbs_alg, gbs_ref, gflops) in rows.items():
-        assert us > 0 and gbs_alg > 0 and gflops > 0, (name, us)
+        assert us > 0 and gbs_alg > 0 and gflops >= 0, (name, us)  # (%.1f of a 100-row dot rounds to 0.0)
     prob = hostapi.Problem(pa[0], pa[1], pa[2], pa[3], fmt=fmt.lower(), Cc=64, sigma=32)
     alg = prob.spmv_bytes()
     m = re.search(r"spMVM moves ([0-9.]+) MB per launch \(reference layout: ([0-9.]+) MB", txt)

@@ -37,36 +37,26 @@ def gpu_spmv(L, m, x, nr):
     dx, dy = DeviceVector.from_host(x), DeviceVector(nr)
     L.sb_spmv(m, dx.ptr, dy.ptr)
     y = dy.get()
-    if L.sb_matrix_pack_level(m) == 0 and L.sb_matrix_pattern_classes(m) > 0:
-        # CRS with a private pattern mirror: native kernel (0) and mirror (3) must agree
-        best = L.sb_matrix_packed_mode(m)
-        assert best in (0, 3)
-        for mode in (0, 3):
-            L.sb_matrix_use_packed(m, mode)
-            assert L.sb_matrix_packed_mode(m) == mode
-            dy.set(np.full(nr, 7.0))
-            L.sb_spmv(m, dx.ptr, dy.ptr)
-            y2 = dy.get()
-            nan = np.isnan(y)
-            assert np.array_equal(nan, np.isnan(y2)), "CRS kernel mode %d: NaN rows differ" % mode
-            assert np.array_equal(y[~nan].view(np.uint64), y2[~nan].view(np.uint64)), "CRS kernel mode %d differs" % mode
-        L.sb_matrix_use_packed(m, best)
-    elif L.sb_matrix_pack_level(m) > 0:
-        best = L.sb_matrix_packed_mode(m)
-        # (matrices of at most one round of resident workgroups default to mode 2 even when mode 3 exists)
-        assert best in ((2, 3) if L.sb_matrix_pattern_classes(m) else (2,) if L.sb_matrix_lds_window(m) else (0, 1))  # 1 only where the packed stream is smaller
-        # reference stream / packed + cache gathers / packed + LDS window / pattern codes + LDS window
-        for mode in (0, 1, 2, 3):
-            L.sb_matrix_use_packed(m, mode)
-            dy.set(np.full(nr, 7.0))
-            L.sb_spmv(m, dx.ptr, dy.ptr)
-            y2 = dy.get()
-            # bit-identical; where the result is NaN only the NaN-ness is compared (which NaN
-            # payload an add of two NaNs returns depends on operand order, not on the algorithm)
-            nan = np.isnan(y)
-            assert np.array_equal(nan, np.isnan(y2)), "kernel mode %d: NaN rows differ" % mode
-            assert np.array_equal(y[~nan].view(np.uint64), y2[~nan].view(np.uint64)), "kernel mode %d differs" % mode
-        L.sb_matrix_use_packed(m, best)
+    # every kernel the matrix has (0 reference stream / native CRS, 1 packed + cache gathers, 2 packed + LDS window,
+    # 3 pattern codes + LDS window, 4 row patterns; CRS: through its private mirror) must give the same bits.
+    # Where the result is NaN only the NaN-ness is compared (which NaN payload an add of two NaNs returns depends
+    # on operand order, not on the algorithm)
+    best = L.sb_matrix_packed_mode(m)
+    tried = set()
+    for mode in (0, 1, 2, 3, 4):
+        L.sb_matrix_use_packed(m, mode)
+        got = L.sb_matrix_packed_mode(m)
+        if got in tried:
+            continue
+        tried.add(got)
+        dy.set(np.full(nr, 7.0))
+        L.sb_spmv(m, dx.ptr, dy.ptr)
+        y2 = dy.get()
+        nan = np.isnan(y)
+        assert np.array_equal(nan, np.isnan(y2)), "kernel mode %d: NaN rows differ" % got
+        assert np.array_equal(y[~nan].view(np.uint64), y2[~nan].view(np.uint64)), "kernel mode %d differs" % got
+    assert best in tried
+    L.sb_matrix_use_packed(m, best)
     dx.free(), dy.free()
     return y
 
