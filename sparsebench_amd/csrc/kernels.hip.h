@@ -246,116 +246,89 @@ __global__ __launch_bounds__(256) void spmv_scs_generic(const uint32_t* __restri
 
 // =============================================================================
 // CRS SpMV (reference loop: src/matrix-CRS.c:54-64), streaming the reference's own arrays
-// (12 B per nonzero).  The nonzero stream of a workgroup is cut into tiles of CRS_TILE
-// consecutive nonzeros, whatever the rows look like: per tile the workgroup streams val / col
-// with coalesced non-temporal loads, gathers x, and puts the PRODUCTS into LDS; rows are then
-// summed from LDS left to right -- the CPU's order, hence the CPU's bits -- by one lane per
-// row.  Rows are handled in groups of 64 consecutive rows (= one level-0 group of the
-// canonical dot, so p.Ap partials can be fused exactly as in the Sell-C-sigma kernels): wave w
-// of the workgroup owns groups g0+w, g0+w+4, ...; a lane keeps its row's running sum in a
-// register from tile to tile, so a row (or a group) may span any number of tiles -- very long
-// rows and very short ones need no special case, and idle lanes cost nothing but their share
-// of a 64-lane LDS read.
-// Software pipeline: while the rows of tile j are summed, the gathers of tile j+1 and the stream
-// loads of tile j+2 are in flight (registers), so a workgroup keeps two tiles' worth of HBM
-// requests outstanding; two barriers per tile guard the one product buffer.  Measured on the
-// irregular stand-in (94 M nonzeros): see DESIGN.md section 4.
+// (12 B per nonzero).  Row blocks are cut on the host so that a block's nonzeros fit one LDS
+// tile (<= 2048 nonzeros, <= 256 rows): the workgroup streams val / col with coalesced
+// non-temporal loads (all of a thread's loads issued before the first use), gathers x, and
+// puts the PRODUCTS into LDS; thread r then adds row r's products left to right -- the CPU's
+// order, hence the CPU's bits -- four LDS reads in flight at a time.  A row longer than the
+// tile is walked tile by tile by thread 0 (still in order).  8 workgroups per CU.
+// Measured against it on the same box (round 2, irregular stand-in 94 M nonzeros / HPCG 128^3 inside CG):
+// a software-pipelined kernel with row sums carried from tile to tile, 64-row groups per wave and the
+// p.Ap partials fused -- 260 vs 238 us and 167 vs 151 us, and fewer CG iterations/s even though it saves the
+// separate dot pass (registers and LDS for the pipeline cost half the resident workgroups); and the
+// unbatched summation loop of round 1 -- 159 vs 151 us.  DESIGN.md section 4.
 // =============================================================================
-constexpr int CRS_THREADS    = 256;
-constexpr int CRS_MAX_BATCH  = 8;                           // nonzeros per thread per tile (template parameter: 4 or 8)
-constexpr int CRS_TILE       = CRS_THREADS * CRS_MAX_BATCH; // the largest tile: 2048 nonzeros = 16 KiB of products
-constexpr int CRS_MAX_GROUPS = 16;                          // 64-row groups per workgroup (row extents cached in LDS)
+constexpr int CRS_THREADS = 256;
+constexpr int CRS_TILE  = 2048; // nonzeros per LDS tile (16 KiB: 8 workgroups per CU)
+constexpr int CRS_BATCH = CRS_TILE / CRS_THREADS;
 
-template <bool DOT, int CRS_BATCH>
-__global__ __launch_bounds__(CRS_THREADS) void spmv_crs_rows(const uint32_t* __restrict__ blockGroups,
-    const uint32_t* __restrict__ rowPtr, const uint32_t* __restrict__ colInd, const double* __restrict__ val,
-    const double* __restrict__ x, double* __restrict__ y, uint32_t nr, uint32_t nBlocks, uint32_t blocksPerXcd,
-    double* __restrict__ dotPartials, const int* __restrict__ stop)
+// products of nonzeros [base, end) -> prod[]: all of a thread's loads are issued before
+// the first use (stream loads, then gathers), one HBM + one cache round trip per tile
+__device__ __forceinline__ void crs_products(uint32_t base, uint32_t end, uint32_t t,
+    const uint32_t* __restrict__ colInd, const double* __restrict__ val, const double* __restrict__ x,
+    double* prod)
 {
-  constexpr int CRS_TILE = CRS_THREADS * CRS_BATCH; // (shadows the namespace-level maximum)
+  double v[CRS_BATCH], xv[CRS_BATCH];
+  uint32_t c[CRS_BATCH];
+#pragma unroll
+  for (int u = 0; u < CRS_BATCH; u++) {
+    const uint32_t k = base + t + (uint32_t)u * CRS_THREADS;
+    v[u] = 0.0, c[u] = 0u;
+    if (k < end) v[u] = stream_load(val + k), c[u] = stream_load(colInd + k);
+  }
+#pragma unroll
+  for (int u = 0; u < CRS_BATCH; u++) {
+    const uint32_t k = base + t + (uint32_t)u * CRS_THREADS;
+    xv[u]            = k < end ? x[c[u]] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < CRS_BATCH; u++) {
+    const uint32_t k = base + t + (uint32_t)u * CRS_THREADS;
+    if (k < end) prod[k - base] = v[u] * xv[u];
+  }
+}
+
+__global__ __launch_bounds__(CRS_THREADS) void spmv_crs_stream(
+    const uint32_t* __restrict__ rowBlocks, const uint32_t* __restrict__ rowPtr,
+    const uint32_t* __restrict__ colInd, const double* __restrict__ val,
+    const double* __restrict__ x, double* __restrict__ y, uint32_t nBlocks,
+    uint32_t blocksPerXcd, const int* __restrict__ stop)
+{
   __shared__ double prod[CRS_TILE];
-  __shared__ uint32_t rowp[CRS_MAX_GROUPS * 64 + 4]; // row extents of the workgroup's rows
-  __shared__ double xs[DOT ? CRS_MAX_GROUPS * 64 : 1]; // their x entries (fused p.Ap)
   const int stopped = stop ? *stop : 0;
   const uint32_t lb = xcd_block(blockIdx.x, blocksPerXcd);
-  if (lb >= nBlocks || stopped) return; // uniform per workgroup
-  const uint32_t g0 = blockGroups[lb], g1 = blockGroups[lb + 1]; // groups of 64 rows, g1 - g0 <= CRS_MAX_GROUPS
-  const uint32_t r0 = g0 * 64u, r1 = min(g1 * 64u, nr);
-  const uint32_t t = threadIdx.x, lane = t & 63u;
-  // Everything the summation needs besides the products comes from LDS, filled once: inside the tile loop only
-  // the stream loads and the gathers are vector-memory reads, in an order the hardware's in-order load counter
-  // can wait on selectively (gathers of tile j+1, THEN stream of tile j+2; the products of j+1 wait for the
-  // gathers only).
-  for (uint32_t i = t; i <= r1 - r0; i += CRS_THREADS) rowp[i] = rowPtr[r0 + i];
-  if (DOT)
-    for (uint32_t i = t; i < r1 - r0; i += CRS_THREADS) xs[i] = x[r0 + i];
+  if (lb >= nBlocks || stopped) return;
+  const uint32_t r0 = rowBlocks[lb], r1 = rowBlocks[lb + 1];
   const uint32_t n0 = rowPtr[r0], n1 = rowPtr[r1];
-  const uint32_t last = n1 > n0 ? n1 - 1u : n0; // clamp target: every stream load is unconditional
-  double v[CRS_BATCH], vn[CRS_BATCH], xv[CRS_BATCH];
-  uint32_t c[CRS_BATCH], cn[CRS_BATCH];
-  auto stream = [&](uint32_t base, double* vv, uint32_t* cc) {
-#pragma unroll
-    for (int u = 0; u < CRS_BATCH; u++) {
-      const uint32_t k = min(base + t + (uint32_t)u * CRS_THREADS, last);
-      vv[u] = stream_load(val + k), cc[u] = stream_load(colInd + k);
-    }
-  };
-  stream(n0, v, c);
-  __syncthreads(); // rowp / xs are filled
-#pragma unroll
-  for (int u = 0; u < CRS_BATCH; u++) xv[u] = x[c[u]];
-  stream(n0 + (uint32_t)CRS_TILE, vn, cn);
-  // wave w owns groups g0 + w, g0 + w + 4, ...; lane = row of the group; [a, b) = the row's nonzeros
-  uint32_t g = g0 + (t >> 6);
-  auto extents = [&](uint32_t gg, uint32_t& a, uint32_t& b) {
-    const uint32_t r = gg * 64u + lane;
-    const bool have  = gg < g1 && r < r1;
-    const uint32_t i = have ? r - r0 : 0u;
-    const uint32_t pa = rowp[i], pb = rowp[i + 1u];
-    a = have ? pa : n1, b = have ? pb : n1;
-  };
-  uint32_t a, b;
-  extents(g, a, b);
-  double sum = 0.0;
-  auto finish_group = [&]() { // wave-uniform call: all 64 lanes take part in the butterfly
-    const uint32_t r = g * 64u + lane;
-    if (r < r1) y[r] = sum;
-    if (DOT) {
-      const double tt = butterfly64(r < r1 ? xs[r - r0] * sum : 0.0);
-      if (lane == 0) dotPartials[g] = tt;
-    }
-    g += 4u, sum = 0.0;
-    extents(g, a, b);
-  };
-  const uint32_t nTiles = (n1 - n0 + (uint32_t)CRS_TILE - 1u) / (uint32_t)CRS_TILE;
-  for (uint32_t j = 0; j < nTiles; j++) {
-    const uint32_t base = n0 + j * (uint32_t)CRS_TILE, end = min(base + (uint32_t)CRS_TILE, n1);
-    // products of tile j (slots past `end` hold products of clamped duplicates; no row extent reaches them)
-#pragma unroll
-    for (int u = 0; u < CRS_BATCH; u++) prod[t + (uint32_t)u * CRS_THREADS] = v[u] * xv[u];
+  const uint32_t t = threadIdx.x;
+  if (n1 - n0 <= (uint32_t)CRS_TILE) {
+    const uint32_t r = r0 + t; // this thread's row (if any): fetch its extent early
+    uint32_t a = 0, b = 0;
+    if (r < r1) a = rowPtr[r] - n0, b = rowPtr[r + 1] - n0;
+    crs_products(n0, n1, t, colInd, val, x, prod);
     __syncthreads();
-    // tile j+1: gathers, then tile j+2's stream -- all of it in flight while the rows of tile j are summed
-#pragma unroll
-    for (int u = 0; u < CRS_BATCH; u++) v[u] = vn[u], c[u] = cn[u];
-#pragma unroll
-    for (int u = 0; u < CRS_BATCH; u++) xv[u] = x[c[u]];
-    stream(base + 2u * (uint32_t)CRS_TILE, vn, cn);
-    while (g < g1) { // wave-uniform: this wave's groups that have nonzeros in [base, end)
-      // this lane's piece of its row inside the tile, as offsets into the product buffer
-      const uint32_t lo = max(a, base) - base, hi = max(min(b, end), base) - base;
-      uint32_t k = lo;
-      for (; k + 4u <= hi; k += 4u) { // four LDS reads in flight, then the four adds in order
+    if (r < r1) {
+      double sum = 0.0;
+      uint32_t k = a;
+      for (; k + 4u <= b; k += 4u) { // four LDS reads in flight, then the four adds in order
         const double d0 = prod[k], d1 = prod[k + 1u], d2 = prod[k + 2u], d3 = prod[k + 3u];
         sum = (((sum + d0) + d1) + d2) + d3;
       }
-      for (; k < hi; k++) sum = sum + prod[k];
-      const uint32_t gEnd = (uint32_t)__builtin_amdgcn_readlane((int)b, 63); // rowPtr is monotone: the group's end
-      if (gEnd > end) break; // the group continues in the next tile
-      finish_group();
+      for (; k < b; k++) sum = sum + prod[k];
+      y[r] = sum;
     }
-    __syncthreads(); // the product buffer is free again
+  } else { // one very long row (the host never puts two rows in an oversize block)
+    double sum = 0.0;
+    for (uint32_t base = n0; base < n1; base += CRS_TILE) {
+      const uint32_t end = min(base + (uint32_t)CRS_TILE, n1);
+      __syncthreads();
+      crs_products(base, end, t, colInd, val, x, prod);
+      __syncthreads();
+      if (t == 0)
+        for (uint32_t k = 0; k < end - base; k++) sum = sum + prod[k];
+    }
+    if (t == 0) y[r0] = sum;
   }
-  while (g < g1) finish_group(); // groups without any nonzero behind the last tile (or a workgroup of empty rows)
 }
 
 // =============================================================================

@@ -123,8 +123,8 @@ void sb_cg_counters(const sb_cg* s, int out[5])
 }
 
 static bool spmv_can_fuse_dot(const sb_cg* s)
-{ // p.Ap partials in the SpMV epilogue: every kernel whose waves own whole 64-row groups (SCS C=64, CRS)
-  return s->fused && (s->A->fmt == 1 ? s->A->C == 64 : true);
+{ // p.Ap partials in the SpMV epilogue: the wave-per-chunk kernels (SCS C=64, or CRS through its mirror)
+  return s->fused && (s->A->fmt == 1 ? s->A->C == 64 : spmv_uses_patterns(s->A));
 }
 
 // levels 1-2 of the reduction + the scalar step: one 1-workgroup launch after the producer

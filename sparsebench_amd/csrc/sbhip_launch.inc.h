@@ -31,22 +31,11 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
   if (m->fmt == 0 && spmv_uses_patterns(m)) {
     launch_pat(m->mirror, true, x, y, dotPartials, stop, part, stream ? stream : g.stream, halo);
   } else if (m->fmt == 0) {
+    if (dot) SB_FATAL("the native CRS kernel has no fused dot (its row blocks are not aligned to the 64-row groups of "
+                      "the canonical dot; a kernel that is was measured slower, kernels.hip.h): sbhip_cg adds a dot pass");
     const uint32_t per = (m->nRowBlocks + 7) / 8;
-    static const int crsBatch = getenv("SB_CRS_BATCH") ? atoi(getenv("SB_CRS_BATCH")) : 4; // 4: 240 us, 8: 253 us (irregular, 94 M nnz)
-#define CRS_LAUNCH(DO, BA)                                                                                              \
-  hipLaunchKernelGGL((spmv_crs_rows<DO, BA>), dim3(per * 8), dim3(CRS_THREADS), 0, g.stream, m->rowBlocks, m->rowPtr, \
-      m->colInd, m->val, x, y, m->nr, m->nRowBlocks, per, dotPartials, stop)
-    if (crsBatch == 4) {
-      if (dot) CRS_LAUNCH(true, 4);
-      else CRS_LAUNCH(false, 4);
-    } else if (crsBatch == 2) {
-      if (dot) CRS_LAUNCH(true, 2);
-      else CRS_LAUNCH(false, 2);
-    } else {
-      if (dot) CRS_LAUNCH(true, 8);
-      else CRS_LAUNCH(false, 8);
-    }
-#undef CRS_LAUNCH
+    hipLaunchKernelGGL(spmv_crs_stream, dim3(per * 8), dim3(CRS_THREADS), 0, g.stream, m->rowBlocks, m->rowPtr, m->colInd,
+        m->val, x, y, m->nRowBlocks, per, stop);
   } else if (m->C == 64) {
     if (g_scs_unroll < 0) {
       const char* u = getenv("SB_SCS_UNROLL");

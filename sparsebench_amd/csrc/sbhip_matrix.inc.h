@@ -23,33 +23,23 @@ sb_matrix* sb_crs_upload(uint32_t nr, uint32_t nc, const uint32_t* rowPtr, const
     if (rowPtr[i + 1] < rowPtr[i]) SB_FATAL("CRS rowPtr not monotone at row %u", i);
   for (uint32_t k = 0; k < m->nnz; k++)
     if (colInd[k] >= nc) SB_FATAL("CRS colInd[%u]=%u out of range (nc=%u)", k, colInd[k], nc);
-  if ((uint64_t)m->nnz + 2u * CRS_TILE >= 0xFFFFFFFFull) SB_FATAL("CRS: %u nonzeros leave no room for 32-bit tile arithmetic", m->nnz);
-  // Work decomposition of spmv_crs_rows: a workgroup takes whole groups of 64 rows (the level-0 groups of
-  // the canonical dot) holding about `target` nonzeros -- several tiles, so that its software pipeline has
-  // something to overlap -- but never so many that the grid cannot fill the device (>= ~20 workgroups per CU
-  // where the matrix is big enough).
-  const uint32_t nGroups = (nr + 63u) / 64u;
-  const uint64_t wantBlocks = (uint64_t)g.prop.multiProcessorCount * 20u;
-  uint64_t target = wantBlocks ? (uint64_t)m->nnz / wantBlocks : (uint64_t)m->nnz;
-  target = std::min<uint64_t>(std::max<uint64_t>(target, CRS_TILE), 8u * CRS_TILE);
+  // Row blocks of spmv_crs_stream: as many rows as fit ONE tile of CRS_TILE nonzeros and CRS_THREADS rows; a row
+  // longer than the tile gets a block of its own.
   {
-    const char* e = getenv("SB_CRS_BLOCK_TILES");
-    if (e && atoi(e) > 0) target = (uint64_t)atoi(e) * CRS_TILE;
+    std::vector<uint32_t> rb;
+    rb.push_back(0);
+    uint32_t r = 0;
+    while (r < nr) {
+      const uint32_t start = r, base = rowPtr[r];
+      while (r < nr && r - start < (uint32_t)CRS_THREADS && rowPtr[r + 1] - base <= (uint32_t)CRS_TILE) r++;
+      if (r == start) r++; // single oversize row
+      rb.push_back(r);
+    }
+    m->nRowBlocks = (uint32_t)rb.size() - 1;
+    m->rowBlocks  = (uint32_t*)upload(rb.data(), rb.size() * sizeof(uint32_t));
   }
-  std::vector<uint32_t> rb;
-  rb.push_back(0);
-  uint32_t gi = 0;
-  while (gi < nGroups) {
-    const uint32_t start = gi;
-    const uint64_t base  = rowPtr[(size_t)gi * 64];
-    do gi++;
-    while (gi < nGroups && (uint64_t)rowPtr[std::min<size_t>((size_t)(gi + 1) * 64, nr)] - base <= target && gi - start < (uint32_t)CRS_MAX_GROUPS);
-    rb.push_back(gi);
-  }
-  m->nRowBlocks = (uint32_t)rb.size() - 1;
-  m->rowBlocks  = (uint32_t*)upload(rb.data(), rb.size() * sizeof(uint32_t));
   m->rowPtr     = (uint32_t*)upload(rowPtr, ((size_t)nr + 1) * sizeof(uint32_t));
-  // 64 zeroed elements of slack: the kernel's clamped stream loads of an all-empty tail block read element nnz
+  // (64 zeroed elements of slack behind the arrays)
   HIP_CHECK(hipMalloc(&m->colInd, ((size_t)m->nnz + 64) * sizeof(uint32_t)));
   HIP_CHECK(hipMalloc(&m->val, ((size_t)m->nnz + 64) * sizeof(double)));
   HIP_CHECK(hipMemset(m->colInd + m->nnz, 0, 64 * sizeof(uint32_t)));
