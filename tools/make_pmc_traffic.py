@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Collect the HBM bytes per launch of the SpMV kernels from the PMC passes (tools/prof_run.sh ->
+tools/summarize_prof2.py -> gpurun_out/prof/<tag>/traffic.json) into profiles/<round>_pmc_traffic.json, the file
+bench.py reads roofline.traffic from.  Every entry carries the library version it was collected with: bench.py
+uses an entry only when that matches the library that runs.
+usage: make_pmc_traffic.py <round> "<library version>" <tag>=<workload> [<tag>=<workload> ...]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd, version = sys.argv[1], sys.argv[2]
+out = {"_comment": "HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/prof_run.sh); "
+                   "bytes = 2 * FETCH_SIZE + WRITE_SIZE (gfx950 reports half the bytes of wide coalesced reads; calibration in "
+                   "profiles/r01*_pmc_summary.txt).  bench.py copies bytes_per_launch into roofline.traffic when workload, kernel "
+                   "and library version match.", "library_version": version}
+for spec in sys.argv[3:]:
+    tag, workload = spec.split("=", 1)
+    t = json.load(open(os.path.join(ROOT, "gpurun_out", "prof", tag, "traffic.json")))
+    for k, e in t.items():
+        name = k.split("<")[0].replace("sbk::", "").strip()
+        if not name.startswith("spmv"):
+            continue
+        e = dict(e, library_version=version, source_tag=tag, kernel_instance=k)
+        out.setdefault(workload, {})[name] = e
+path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd)
+json.dump(out, open(path, "w"), indent=1)
+print(open(path).read())
