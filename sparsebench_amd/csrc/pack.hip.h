@@ -226,10 +226,10 @@ __global__ __launch_bounds__(256) void pack_slots_k(const uint32_t* __restrict__
     const uint32_t* __restrict__ chunkLens, const uint32_t* __restrict__ colInd,
     const double* __restrict__ val, const PackMeta* __restrict__ meta,
     const uint32_t* __restrict__ tileSegPtr, const TileSeg* __restrict__ segs, uint32_t nChunks,
-    uint32_t padCol, uint32_t* __restrict__ slotOut)
-{
-  const uint32_t tile  = blockIdx.x;
-  const uint32_t chunk = tile * 4u + (threadIdx.x >> 6);
+    uint32_t padCol, uint32_t* __restrict__ slotOut, uint32_t cpt)
+{ // a block = 4 consecutive chunks; they belong to tile (4 * blockIdx) / cpt (cpt = chunks per tile: 4 or 8)
+  const uint32_t chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t tile  = chunk / cpt;
   const uint32_t lane  = threadIdx.x & 63u;
   if (chunk >= nChunks) return;
   const uint32_t s0 = tileSegPtr[tile], s1 = tileSegPtr[tile + 1];
@@ -381,16 +381,16 @@ __device__ __forceinline__ void pat_fetch(const uint32_t* __restrict__ slots,
   vcode             = (codes[p] >> (8u * (j & 3u))) & 255u;
 }
 
-__global__ __launch_bounds__(256) void pat_collect_k(const PackMeta* __restrict__ meta,
+__global__ __launch_bounds__(512) void pat_collect_k(const PackMeta* __restrict__ meta,
     const uint32_t* __restrict__ slots, const uint32_t* __restrict__ codes, uint32_t nChunks,
     uint16_t* __restrict__ rowBase, uint32_t* __restrict__ tileCount, uint32_t* __restrict__ tileKeys)
-{
+{ // one workgroup per tile, one wave per chunk (blockDim = 64 * chunks per tile)
   __shared__ uint32_t table[1024];
   __shared__ uint32_t count, outPos;
   const uint32_t tile  = blockIdx.x;
-  const uint32_t chunk = tile * 4u + (threadIdx.x >> 6);
+  const uint32_t chunk = tile * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint32_t lane  = threadIdx.x & 63u;
-  for (uint32_t i = threadIdx.x; i < 1024u; i += 256u) table[i] = PAT_EMPTY;
+  for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x) table[i] = PAT_EMPTY;
   if (threadIdx.x == 0) count = 0u, outPos = 0u;
   __syncthreads();
   if (chunk < nChunks) {
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void pat_collect_k(const PackMeta* __restrict_
       const uint32_t key = pat_key(slot, base, vcode);
       uint32_t h         = (key * 2654435761u) >> 22; // 10 bits
       // every thread re-reads count before probing, so the table (1024) never fills:
-      // at most PAT_MAX + 256 distinct keys get in
+      // at most PAT_MAX + blockDim (<= 512) distinct keys get in
       while (*(volatile uint32_t*)&count <= PAT_MAX) {
         const uint32_t old = atomicCAS(&table[h], PAT_EMPTY, key);
         if (old == PAT_EMPTY) {
@@ -420,20 +420,20 @@ __global__ __launch_bounds__(256) void pat_collect_k(const PackMeta* __restrict_
   __syncthreads();
   if (threadIdx.x == 0) tileCount[tile] = count;
   if (count <= PAT_MAX)
-    for (uint32_t i = threadIdx.x; i < 1024u; i += 256u)
+    for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x)
       if (table[i] != PAT_EMPTY) tileKeys[(size_t)tile * 256 + atomicAdd(&outPos, 1u)] = table[i];
 }
 
-__global__ __launch_bounds__(256) void pat_encode_k(const PackMeta* __restrict__ meta,
+__global__ __launch_bounds__(512) void pat_encode_k(const PackMeta* __restrict__ meta,
     const uint32_t* __restrict__ slots, const uint32_t* __restrict__ codes, uint32_t nChunks,
     const uint16_t* __restrict__ rowBase, const uint32_t* __restrict__ tileClass,
     const uint32_t* __restrict__ classKeys, uint32_t* __restrict__ jcodes)
 {
   __shared__ uint32_t keys[256]; // ascending, padded with PAT_EMPTY
-  const uint32_t tile  = blockIdx.x;
-  const uint32_t chunk = tile * 4u + (threadIdx.x >> 6);
+  const uint32_t tile  = blockIdx.x; // one workgroup per tile, one wave per chunk
+  const uint32_t chunk = tile * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint32_t lane  = threadIdx.x & 63u;
-  keys[threadIdx.x]    = classKeys[(size_t)tileClass[tile] * 256 + threadIdx.x];
+  if (threadIdx.x < 256u) keys[threadIdx.x] = classKeys[(size_t)tileClass[tile] * 256 + threadIdx.x];
   __syncthreads();
   if (chunk >= nChunks) return;
   const PackMeta m    = meta[chunk];
@@ -524,7 +524,7 @@ struct HaloWait {
   int* stopw;             // CgScalars::stop, raised together with err: no iterating on a stale halo
   long long timeoutTicks; // bound of the wait (HaloPush::timeoutTicks)
 };
-constexpr uint32_t PAT_EXC_LDS_MAX   = 1024; // exception entries per tile (16 KiB of LDS) at most
+constexpr uint32_t PAT_EXC_LDS_MAX   = 1024; // exception entries per 4 chunks of a tile (16 KiB of LDS) at most
 
 // dominant code sequence of every chunk (majority of the 64 lanes) and the lanes that differ
 __global__ __launch_bounds__(256) void pat_dominant_k(const PackMeta* __restrict__ meta,
@@ -563,7 +563,8 @@ __global__ __launch_bounds__(256) void pat_compact_k(const PackMeta* __restrict_
     const uint32_t* __restrict__ jcodes, uint32_t nChunks, const uint32_t* __restrict__ chunkOff,
     const uint32_t* __restrict__ chunkFlags, const uint32_t* __restrict__ excMask,
     const uint16_t* __restrict__ rowBase, const uint32_t* __restrict__ tileClass,
-    const PatEntry* __restrict__ classDict, uint32_t* __restrict__ stream, PatEntry* __restrict__ excRows)
+    const PatEntry* __restrict__ classDict, uint32_t* __restrict__ stream, PatEntry* __restrict__ excRows,
+    uint32_t cpt)
 {
   const uint32_t chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
   const uint32_t lane  = threadIdx.x & 63u;
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(256) void pat_compact_k(const PackMeta* __restrict_
     const bool isExc  = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
     const uint32_t ix = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
     if (isExc) {
-      const PatEntry* cd   = classDict + (size_t)tileClass[blockIdx.x] * 256;
+      const PatEntry* cd   = classDict + (size_t)tileClass[chunk / cpt] * 256;
       const uint32_t base8 = (uint32_t)rowBase[(size_t)chunk * 64 + lane] << 3;
       for (uint32_t j = 0; j < len; j++) {
         const PatEntry e = cd[(c[(size_t)(j >> 2) * 64] >> (8u * (j & 3u))) & 255u];
@@ -598,8 +599,13 @@ __global__ __launch_bounds__(256) void pat_compact_k(const PackMeta* __restrict_
 // SKIPPAD: padded elements are NOT added (the reference's Sell-C-sigma loop adds 0.0 * x[0]
 // for them, src/matrix-SCS.c:151-155 / :208-227; its CRS loop has no such elements,
 // src/matrix-CRS.c:46-65) -- the instantiation behind the CRS format's private mirror.
-template <bool DOT, bool SKIPPAD, bool HALO>
-__global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict__ hdrs,
+// CPT: chunks per tile, 4 or 8.  With 8 a wave multiplies two chunks (w and w + 4 of the tile) behind ONE header
+// fetch, one window staging and one barrier: those phases take about as long for 8 chunks as for 4 (measured,
+// DESIGN 4.2), the window holds 25 % fewer entries per row, and a CU gets through its tiles in fewer rounds.  The
+// 8-chunk header is two 48-word halves interleaved word by word (X: the tile-level fields and chunks 0-3, Y: the
+// per-chunk fields of chunks 4-7 in the same positions), fetched as ONE 8-byte vector load.
+template <int CPT, bool DOT, bool SKIPPAD, bool HALO>
+__global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict__ hdrWords,
     const uint32_t* __restrict__ stream, const uint16_t* __restrict__ rowBase,
     const PatEntry* __restrict__ classDict, const PatEntry* __restrict__ rowPats,
     const PatEntry* __restrict__ excRows, const TileSeg* __restrict__ segs,
@@ -611,8 +617,11 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   PatEntry* sd = reinterpret_cast<PatEntry*>(lds);
   PatEntry* se = sd + dictEntries;
   double* sx   = reinterpret_cast<double*>(se + excLds + 8u);
-  constexpr int PF = 8; // code groups prefetched (32 columns); wider chunks stream the rest
-  constexpr int WB = 12; // window entries per thread in the first pass
+  constexpr int CW   = CPT / 4;          // chunks per wave
+  constexpr int PF   = 8;                // code groups prefetched (32 columns); wider chunks stream the rest
+  constexpr int LONG = CPT == 8 ? 4 : 3; // loads per thread for each of the three long segments of a simple window
+  constexpr int WB   = 3 * LONG + 3;     // window entries per thread in the first pass
+  constexpr int EXL  = CPT / 2;          // unconditional exception loads per thread (256 entries each)
   // A launch covers headers [firstHdr, firstHdr + nHdrs).  Headers are stored with the tiles
   // that touch no halo column first, so that on several ranks the interior part of the
   // product can run while the halo is still in flight (one launch for each part).
@@ -621,21 +630,23 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   // round trip 1: ONE vector load brings the tile header (lanes 0..47) and the stop flag
   // (lane 48); fields are then read out of the lanes (v_readlane -> SGPRs)
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t* hp  = reinterpret_cast<const uint32_t*>(hdrs + hidx);
-  const uint32_t hv   = *(lane < (uint32_t)PAT_STOP_LANE ? hp + lane : reinterpret_cast<const uint32_t*>(stop));
-  auto field = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)hv, i); };
+  uint32_t hvx, hvy = 0u;
+  if (CPT == 4) {
+    const uint32_t* hp = hdrWords + (size_t)hidx * 48u;
+    hvx = *(lane < (uint32_t)PAT_STOP_LANE ? hp + lane : reinterpret_cast<const uint32_t*>(stop));
+  } else {
+    const u32x2* hp = reinterpret_cast<const u32x2*>(hdrWords + (size_t)hidx * 128u);
+    const u32x2 h2  = *(lane < (uint32_t)PAT_STOP_LANE ? hp + lane : reinterpret_cast<const u32x2*>(stop));
+    hvx = h2.x, hvy = h2.y;
+  }
+  auto field = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)hvx, i); };
+  // per-chunk field of the wave's c-th chunk (chunk wv + 4 c of the tile): half X for c = 0, half Y for c = 1
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  auto cfield = [&](int c, int i) -> uint32_t {
+    return (uint32_t)__builtin_amdgcn_readlane((int)(c == 0 ? hvx : hvy), i);
+  };
   const int stopped    = (int)field(PAT_STOP_LANE);
-  const uint32_t wv    = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t tile  = field(46);
-  const uint32_t chunk = tile * 4u + wv;
-  const uint32_t row   = chunk * 64u + lane;
-  const bool active    = chunk < nChunks; // wave-uniform; inactive waves still help staging
-  const uint32_t off   = (uint32_t)__builtin_amdgcn_readlane((int)hv, 4 + (int)wv);
-  const uint32_t lenf  = (uint32_t)__builtin_amdgcn_readlane((int)hv, 8 + (int)wv);
-  const uint32_t len = lenf & ~(PAT_UNIFORM | PAT_NOPAD), ng = (len + 3u) >> 2;
-  const bool uni     = (lenf & PAT_UNIFORM) != 0u; // wave-uniform
-  const uint32_t excLo = (uint32_t)__builtin_amdgcn_readlane((int)hv, 36 + 2 * (int)wv);
-  const uint32_t excHi = (uint32_t)__builtin_amdgcn_readlane((int)hv, 37 + 2 * (int)wv);
   const uint32_t cls = field(0), nseg = field(1), winInline = field(30), flags = field(31);
   const uint32_t excStart = field(44), excCount = field(45);
   const bool simple = (flags & PAT_SIMPLE_WINDOW) != 0u; // uniform per workgroup
@@ -660,36 +671,49 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   };
   // round trip 2: codes (L chunks), row bases, own x entries, tables, x window -- addresses
   // clamped into valid memory so that nothing waits for a branch
-  const bool isExc      = uni && ((lane < 32u ? excLo >> lane : excHi >> (lane - 32u)) & 1u) != 0u;
-  const uint32_t excIdx = __builtin_amdgcn_mbcnt_hi(excHi, __builtin_amdgcn_mbcnt_lo(excLo, 0u));
-  const uint32_t gLast  = ng ? ng - 1u : 0u;
-  const uint32_t* cbase = stream + (size_t)(uni ? 0u : off) + lane;
+  uint32_t chunk[CW], row[CW], off[CW], lenf[CW];
+  int32_t base[CW];
+  double xrow[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    chunk[c] = tile * CPT + wv + 4u * (uint32_t)c;
+    row[c]   = chunk[c] * 64u + lane;
+    off[c]   = cfield(c, 4 + (int)wv);
+    lenf[c]  = cfield(c, 8 + (int)wv);
+    base[c]  = (int32_t)rowBase[chunk[c] < nChunks ? row[c] : 0u];
+    xrow[c]  = DOT ? x[min(row[c], nr - 1u)] : 0.0;
+  }
+  // (per-lane code words are prefetched for the wave's FIRST chunk only; a second L chunk fetches its own later:
+  //  matrices that come here in the 8-chunk form are made of U chunks almost everywhere)
+  const bool uni0       = (lenf[0] & PAT_UNIFORM) != 0u; // wave-uniform
+  const uint32_t len0   = lenf[0] & ~(PAT_UNIFORM | PAT_NOPAD), ng0 = (len0 + 3u) >> 2;
+  const uint32_t gLast0 = ng0 ? ng0 - 1u : 0u;
   uint32_t cw[PF];
 #pragma unroll
   for (int gi = 0; gi < PF; gi++) cw[gi] = 0u;
-  if (!uni) {
+  if (!uni0) {
+    const uint32_t* cb0 = stream + (size_t)off[0] + lane;
 #pragma unroll
-    for (int gi = 0; gi < PF; gi++) cw[gi] = stream_load(cbase + (size_t)min((uint32_t)gi, gLast) * 64);
+    for (int gi = 0; gi < PF; gi++) cw[gi] = stream_load(cb0 + (size_t)min((uint32_t)gi, gLast0) * 64);
   }
-  const int32_t base = (int32_t)rowBase[active ? row : 0u];
-  const double xrow  = DOT ? x[min(row, nr - 1u)] : 0.0;
-  PatEntry mine      = { 0.0, 0u, 0u };
+  PatEntry mine = { 0.0, 0u, 0u };
   if (dictEntries) mine = classDict[(size_t)cls * 256 + threadIdx.x];
-  const PatEntry ex0 = excRows[(size_t)excStart + threadIdx.x]; // excRows carries 512 entries of slack
-  const PatEntry ex1 = excRows[(size_t)excStart + 256u + threadIdx.x];
-  const double xpad  = x[padCol]; // slot 0: what padding multiplies (src/matrix-SCS.c:151-155)
+  PatEntry ex[EXL];
+#pragma unroll
+  for (int q = 0; q < EXL; q++) ex[q] = excRows[(size_t)excStart + (uint32_t)q * 256u + threadIdx.x]; // (slack behind excRows)
+  const double xpad = x[padCol]; // slot 0: what padding multiplies (src/matrix-SCS.c:151-155)
   double t[WB];
   if (simple) { // segment by segment: entry i of segment s -> slot first_s + i
 #pragma unroll
     for (int sI = 0; sI < 3; sI++) {
       const uint32_t sc = field(12 + 3 * sI), sn = field(12 + 3 * sI + 2);
 #pragma unroll
-      for (int r = 0; r < 3; r++) t[sI * 3 + r] = xcol(sn ? sc + min((uint32_t)r * 256u + threadIdx.x, sn - 1u) : padCol);
+      for (int r = 0; r < LONG; r++) t[sI * LONG + r] = xcol(sn ? sc + min((uint32_t)r * 256u + threadIdx.x, sn - 1u) : padCol);
     }
 #pragma unroll
     for (int sI = 3; sI < 6; sI++) {
       const uint32_t sc = field(12 + 3 * sI), sn = field(12 + 3 * sI + 2);
-      t[6 + sI] = xcol(sn ? sc + min(threadIdx.x, sn - 1u) : padCol);
+      t[3 * LONG + sI - 3] = xcol(sn ? sc + min(threadIdx.x, sn - 1u) : padCol);
     }
   } else { // slot by slot over the inline segments
     uint32_t segCol[PAT_INLINE_SEGS], segFirst[PAT_INLINE_SEGS];
@@ -705,11 +729,15 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
     }
   }
   // keep every load above in front of the exit test (the compiler would sink them behind it)
-  asm volatile("" ::"v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]),
-               "v"(t[8]), "v"(t[9]), "v"(t[10]), "v"(t[11]), "v"(xpad));
-  asm volatile("" ::"v"(cw[0]), "v"(cw[1]), "v"(cw[2]), "v"(cw[3]), "v"(cw[4]), "v"(cw[5]), "v"(cw[6]),
-               "v"(cw[7]), "v"(base), "v"(xrow), "v"(mine.v), "v"(mine.off8), "v"(mine.m));
-  asm volatile("" ::"v"(ex0.v), "v"(ex0.off8), "v"(ex1.v), "v"(ex1.off8));
+#pragma unroll
+  for (int k = 0; k < WB; k++) asm volatile("" ::"v"(t[k]));
+#pragma unroll
+  for (int gi = 0; gi < PF; gi++) asm volatile("" ::"v"(cw[gi]));
+#pragma unroll
+  for (int c = 0; c < CW; c++) asm volatile("" ::"v"(base[c]), "v"(xrow[c]));
+#pragma unroll
+  for (int q = 0; q < EXL; q++) asm volatile("" ::"v"(ex[q].v), "v"(ex[q].off8));
+  asm volatile("" ::"v"(xpad), "v"(mine.v), "v"(mine.off8), "v"(mine.m));
   if (tile0 >= nHdrs || stopped) return; // uniform per workgroup
   if (simple) {
     if (threadIdx.x == 0) sx[0] = xpad;
@@ -717,15 +745,15 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
     for (int sI = 0; sI < 3; sI++) {
       const uint32_t sf = field(12 + 3 * sI + 1), sn = field(12 + 3 * sI + 2);
 #pragma unroll
-      for (int r = 0; r < 3; r++) {
+      for (int r = 0; r < LONG; r++) {
         const uint32_t i = (uint32_t)r * 256u + threadIdx.x;
-        if (i < sn) sx[sf + i] = t[sI * 3 + r];
+        if (i < sn) sx[sf + i] = t[sI * LONG + r];
       }
     }
 #pragma unroll
     for (int sI = 3; sI < 6; sI++) {
       const uint32_t sf = field(12 + 3 * sI + 1), sn = field(12 + 3 * sI + 2);
-      if (threadIdx.x < sn) sx[sf + threadIdx.x] = t[6 + sI];
+      if (threadIdx.x < sn) sx[sf + threadIdx.x] = t[3 * LONG + sI - 3];
     }
   } else {
     uint32_t segCol[PAT_INLINE_SEGS], segFirst[PAT_INLINE_SEGS];
@@ -751,135 +779,151 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const TileHdr* __restrict_
   }
   // offsets become LDS byte addresses here (once per staged entry, not once per use)
   const uint32_t sxOff = (dictEntries + excLds + 8u) * (uint32_t)sizeof(PatEntry);
-  if (threadIdx.x < excCount) se[threadIdx.x] = PatEntry{ ex0.v, ex0.off8 + sxOff, ex0.m };
-  if (threadIdx.x + 256u < excCount) se[threadIdx.x + 256u] = PatEntry{ ex1.v, ex1.off8 + sxOff, ex1.m };
-  for (uint32_t i = 512u + threadIdx.x; i < excCount; i += 256u) {
+#pragma unroll
+  for (int q = 0; q < EXL; q++) {
+    const uint32_t i = (uint32_t)q * 256u + threadIdx.x;
+    if (i < excCount) se[i] = PatEntry{ ex[q].v, ex[q].off8 + sxOff, ex[q].m };
+  }
+  for (uint32_t i = (uint32_t)EXL * 256u + threadIdx.x; i < excCount; i += 256u) {
     const PatEntry e = excRows[(size_t)excStart + i];
     se[i]            = PatEntry{ e.v, e.off8 + sxOff, e.m };
   }
   if (dictEntries) sd[threadIdx.x] = PatEntry{ mine.v, mine.off8 + sxOff, mine.m };
   __syncthreads();
-  if (!active) return;
   // An element costs: entry -> byte offset of its x in the window -> x -> multiply -> add.
   // Offsets are pre-scaled (base8 * m + off8, m = 0 for padding), and only a chunk's last,
   // partial group pays for the "column < width" selects.
-  double acc           = 0.0;
-  const uint32_t base8 = (uint32_t)base << 3;
   auto xread = [&](uint32_t o) -> double { // o: LDS byte address
     return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds) + o);
   };
-  const uint32_t base8x = base8 + sxOff;
-  if (uni) {
-    // dominant lanes: entries of the row pattern from scalar registers (s_load through the
-    // scalar cache); exception lanes: their own ready-made entries from LDS.  Two groups
-    // (8 columns) at a time, so that 8 entry loads / 8 x reads are in flight together.
-    const PatEntry* rp = rowPats + (uint32_t)__builtin_amdgcn_readlane((int)hv, 32 + (int)wv);
-    const PatEntry* me = se + ((off - excStart) + excIdx * len); // this lane's row, if it is an exception
-    const bool nopad   = (lenf & PAT_NOPAD) != 0u; // wave-uniform: no padding in the dominant pattern
-    auto upair = [&](uint32_t j0, const bool full, const bool np) {
-      double v[8], xs[8];
-      uint32_t o[8], keep[8];
 #pragma unroll
-      for (uint32_t q = 0; q < 8; q++) {
-        const PatEntry e = rp[full ? j0 + q : min(j0 + q, len - 1u)]; // uniform address: s_load
-        keep[q]          = np ? 1u : e.m;
-        // (pinned to scalar registers: otherwise the compiler merges this load with the odd
-        //  lanes' LDS read below into ONE flat load through a selected generic pointer)
-        const unsigned long long vb = __builtin_bit_cast(unsigned long long, e.v);
-        const unsigned long long vs =
-            (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vb) |
-            ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(vb >> 32)) << 32);
-        v[q] = __builtin_bit_cast(double, vs);
-        o[q] = np ? base8x + e.off8 : __umul24(base8, e.m) + (e.off8 + sxOff);
-      }
-      if (isExc) { // divergent: only the odd lanes
+  for (int c = 0; c < CW; c++) {
+    if (chunk[c] >= nChunks) continue; // wave-uniform; inactive waves only helped staging
+    const uint32_t len = lenf[c] & ~(PAT_UNIFORM | PAT_NOPAD), ng = (len + 3u) >> 2;
+    const bool uni     = (lenf[c] & PAT_UNIFORM) != 0u; // wave-uniform
+    double acc           = 0.0;
+    const uint32_t base8 = (uint32_t)base[c] << 3;
+    const uint32_t base8x = base8 + sxOff;
+    if (uni) {
+      // dominant lanes: entries of the row pattern from scalar registers (s_load through the
+      // scalar cache); exception lanes: their own ready-made entries from LDS.  Two groups
+      // (8 columns) at a time, so that 8 entry loads / 8 x reads are in flight together.
+      const uint32_t excLo = cfield(c, 36 + 2 * (int)wv), excHi = cfield(c, 37 + 2 * (int)wv);
+      const bool isExc      = ((lane < 32u ? excLo >> lane : excHi >> (lane - 32u)) & 1u) != 0u;
+      const uint32_t excIdx = __builtin_amdgcn_mbcnt_hi(excHi, __builtin_amdgcn_mbcnt_lo(excLo, 0u));
+      const PatEntry* rp = rowPats + cfield(c, 32 + (int)wv);
+      const PatEntry* me = se + ((off[c] - excStart) + excIdx * len); // this lane's row, if it is an exception
+      const bool nopad   = (lenf[c] & PAT_NOPAD) != 0u; // wave-uniform: no padding in the dominant pattern
+      auto upair = [&](uint32_t j0, const bool full, const bool np) {
+        double v[8], xs[8];
+        uint32_t o[8], keep[8];
 #pragma unroll
         for (uint32_t q = 0; q < 8; q++) {
-          const PatEntry e = me[j0 + q]; // entries past the row's end belong to the next row / the slack
-          v[q]             = e.v;
-          o[q]             = e.off8;
-          if (SKIPPAD) keep[q] = e.m;
+          const PatEntry e = rp[full ? j0 + q : min(j0 + q, len - 1u)]; // uniform address: s_load
+          keep[q]          = np ? 1u : e.m;
+          // (pinned to scalar registers: otherwise the compiler merges this load with the odd
+          //  lanes' LDS read below into ONE flat load through a selected generic pointer)
+          const unsigned long long vb = __builtin_bit_cast(unsigned long long, e.v);
+          const unsigned long long vs =
+              (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vb) |
+              ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(vb >> 32)) << 32);
+          v[q] = __builtin_bit_cast(double, vs);
+          o[q] = np ? base8x + e.off8 : __umul24(base8, e.m) + (e.off8 + sxOff);
         }
-      }
+        if (isExc) { // divergent: only the odd lanes
 #pragma unroll
-      for (uint32_t q = 0; q < 8; q++) xs[q] = xread(o[q]);
+          for (uint32_t q = 0; q < 8; q++) {
+            const PatEntry e = me[j0 + q]; // entries past the row's end belong to the next row / the slack
+            v[q]             = e.v;
+            o[q]             = e.off8;
+            if (SKIPPAD) keep[q] = e.m;
+          }
+        }
 #pragma unroll
-      for (uint32_t q = 0; q < 8; q++) {
-        const double prod = v[q] * xs[q];
-        const double sum  = acc + prod;
-        acc               = ((full || j0 + q < len) && (!SKIPPAD || keep[q] != 0u)) ? sum : acc;
-      }
-    };
-    auto uquad = [&](uint32_t j0) { // a chunk's last 1..4 columns
-      double v[4], xs[4];
-      uint32_t o[4], keep[4];
+        for (uint32_t q = 0; q < 8; q++) xs[q] = xread(o[q]);
 #pragma unroll
-      for (uint32_t q = 0; q < 4; q++) {
-        const PatEntry e = rp[min(j0 + q, len - 1u)];
-        keep[q]          = e.m;
-        const unsigned long long vb = __builtin_bit_cast(unsigned long long, e.v);
-        const unsigned long long vs =
-            (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vb) |
-            ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(vb >> 32)) << 32);
-        v[q] = __builtin_bit_cast(double, vs);
-        o[q] = __umul24(base8, e.m) + (e.off8 + sxOff);
-      }
-      if (isExc) {
+        for (uint32_t q = 0; q < 8; q++) {
+          const double prod = v[q] * xs[q];
+          const double sum  = acc + prod;
+          acc               = ((full || j0 + q < len) && (!SKIPPAD || keep[q] != 0u)) ? sum : acc;
+        }
+      };
+      auto uquad = [&](uint32_t j0) { // a chunk's last 1..4 columns
+        double v[4], xs[4];
+        uint32_t o[4], keep[4];
 #pragma unroll
         for (uint32_t q = 0; q < 4; q++) {
-          const PatEntry e = me[j0 + q];
-          v[q]             = e.v;
-          o[q]             = e.off8;
-          if (SKIPPAD) keep[q] = e.m;
+          const PatEntry e = rp[min(j0 + q, len - 1u)];
+          keep[q]          = e.m;
+          const unsigned long long vb = __builtin_bit_cast(unsigned long long, e.v);
+          const unsigned long long vs =
+              (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vb) |
+              ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(vb >> 32)) << 32);
+          v[q] = __builtin_bit_cast(double, vs);
+          o[q] = __umul24(base8, e.m) + (e.off8 + sxOff);
         }
-      }
+        if (isExc) {
 #pragma unroll
-      for (uint32_t q = 0; q < 4; q++) xs[q] = xread(o[q]);
+          for (uint32_t q = 0; q < 4; q++) {
+            const PatEntry e = me[j0 + q];
+            v[q]             = e.v;
+            o[q]             = e.off8;
+            if (SKIPPAD) keep[q] = e.m;
+          }
+        }
 #pragma unroll
-      for (uint32_t q = 0; q < 4; q++) {
-        const double prod = v[q] * xs[q];
-        const double sum  = acc + prod;
-        acc               = (j0 + q < len && (!SKIPPAD || keep[q] != 0u)) ? sum : acc;
+        for (uint32_t q = 0; q < 4; q++) xs[q] = xread(o[q]);
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+          const double prod = v[q] * xs[q];
+          const double sum  = acc + prod;
+          acc               = (j0 + q < len && (!SKIPPAD || keep[q] != 0u)) ? sum : acc;
+        }
+      };
+      uint32_t j0 = 0;
+      for (; j0 + 8u <= len; j0 += 8u) {
+        if (nopad) upair(j0, true, true);
+        else upair(j0, true, false);
       }
-    };
-    uint32_t j0 = 0;
-    for (; j0 + 8u <= len; j0 += 8u) {
-      if (nopad) upair(j0, true, true);
-      else upair(j0, true, false);
+      if (j0 + 4u < len) upair(j0, false, false); // 5..7 columns left
+      else if (j0 < len) uquad(j0);              // 1..4 columns left
+    } else {
+      // per-lane codes; the 4 table reads and then the 4 x reads of a group are in flight
+      // together, columns past the chunk's width are computed but not added
+      const uint32_t* cbase = stream + (size_t)off[c] + lane;
+      auto group = [&](uint32_t cwv, uint32_t j0, const bool full) {
+        PatEntry e[4];
+        double xs[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) e[q] = sd[(cwv >> (8u * q)) & 255u];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) xs[q] = xread(__umul24(base8, e[q].m) + e[q].off8);
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+          const double prod = e[q].v * xs[q];
+          const double sum  = acc + prod;
+          acc               = ((full || j0 + q < len) && (!SKIPPAD || e[q].m != 0u)) ? sum : acc;
+        }
+      };
+      auto pick = [&](uint32_t cwv, uint32_t j0) {
+        if (j0 + 4u <= len) group(cwv, j0, true);
+        else group(cwv, j0, false);
+      };
+      if (c == 0) {
+#pragma unroll
+        for (int gi = 0; gi < PF; gi++)
+          if ((uint32_t)gi < ng) pick(cw[gi], (uint32_t)gi * 4u);
+        for (uint32_t g = PF; g < ng; g++) pick(stream_load(cbase + (size_t)g * 64), g * 4u);
+      } else {
+        for (uint32_t g = 0; g < ng; g++) pick(stream_load(cbase + (size_t)g * 64), g * 4u);
+      }
     }
-    if (j0 + 4u < len) upair(j0, false, false); // 5..7 columns left
-    else if (j0 < len) uquad(j0);              // 1..4 columns left
-  } else {
-    // per-lane codes; the 4 table reads and then the 4 x reads of a group are in flight
-    // together, columns past the chunk's width are computed but not added
-    auto group = [&](uint32_t cwv, uint32_t j0, const bool full) {
-      PatEntry e[4];
-      double xs[4];
-#pragma unroll
-      for (uint32_t q = 0; q < 4; q++) e[q] = sd[(cwv >> (8u * q)) & 255u];
-#pragma unroll
-      for (uint32_t q = 0; q < 4; q++) xs[q] = xread(__umul24(base8, e[q].m) + e[q].off8);
-#pragma unroll
-      for (uint32_t q = 0; q < 4; q++) {
-        const double prod = e[q].v * xs[q];
-        const double sum  = acc + prod;
-        acc               = ((full || j0 + q < len) && (!SKIPPAD || e[q].m != 0u)) ? sum : acc;
-      }
-    };
-    auto pick = [&](uint32_t cwv, uint32_t j0) {
-      if (j0 + 4u <= len) group(cwv, j0, true);
-      else group(cwv, j0, false);
-    };
-#pragma unroll
-    for (int gi = 0; gi < PF; gi++)
-      if ((uint32_t)gi < ng) pick(cw[gi], (uint32_t)gi * 4u);
-    for (uint32_t g = PF; g < ng; g++) pick(stream_load(cbase + (size_t)g * 64), g * 4u);
-  }
-  if (row < nr) y[row] = acc;
-  if (DOT) {
-    double t2 = row < nr ? xrow * acc : 0.0;
-    t2        = butterfly64(t2);
-    if (lane == 0) dotPartials[chunk] = t2;
+    if (row[c] < nr) y[row[c]] = acc;
+    if (DOT) {
+      double t2 = row[c] < nr ? xrow[c] * acc : 0.0;
+      t2        = butterfly64(t2);
+      if (lane == 0) dotPartials[chunk[c]] = t2;
+    }
   }
 }
 

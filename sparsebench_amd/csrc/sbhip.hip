@@ -200,11 +200,14 @@ struct sb_matrix {
   uint16_t* rowBase     = nullptr;
   uint32_t *tileClass = nullptr, *jcodes = nullptr;
   PatEntry* classDict   = nullptr;
-  TileHdr* tileHdrs     = nullptr;
+  uint32_t* tileHdrs    = nullptr; // TileHdr words: 48 per 4-chunk tile, 128 (two interleaved halves) per 8-chunk tile
   PatEntry* rowPats     = nullptr; // level 5: shared row patterns
   PatEntry* excRows     = nullptr; // level 5: expanded exception rows of the U chunks
   uint32_t patDict = 0, patExcLds = 0; // LDS layout of spmv_scs64_pat: table entries, exception entries
   uint32_t patInterior = 0;            // headers [0, patInterior): tiles that touch no halo column
+  // the pattern kernel's tiles: patCPT = 4 or 8 chunks, with their own windows when that differs from level 3's 4
+  uint32_t patCPT = 4, patNTiles = 0, patWindow = 0;
+  TileSeg* patSegs = nullptr; // == tileSegs when patCPT == 4
   // CRS: a private Sell-64-1 mirror carrying only the pattern levels (SKIPPAD kernel); usePacked
   // 3 = product through the mirror, 0 = native CRS kernel
   sb_matrix* mirror = nullptr;

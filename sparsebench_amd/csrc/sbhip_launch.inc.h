@@ -16,7 +16,7 @@ static bool spmv_uses_patterns(const sb_matrix* m)
 static bool spmv_can_split(const sb_matrix* m)
 {
   const sb_matrix* pm = pat_of(m);
-  return spmv_uses_patterns(m) && pm->patInterior > 0 && pm->patInterior < (pm->nChunks + 3) / 4;
+  return spmv_uses_patterns(m) && pm->patInterior > 0 && pm->patInterior < pm->patNTiles;
 }
 static void launch_pat(const sb_matrix* pm, bool skipPad, const double* x, double* y, double* dotPartials,
     const int* stop, int part, hipStream_t stream, const HaloWait* halo);
@@ -110,29 +110,35 @@ static void launch_pat(const sb_matrix* pm, bool skipPad, const double* x, doubl
   memset(&hw, 0, sizeof hw);
   if (halo) hw = *halo;
   const bool dot         = dotPartials != nullptr;
-  const uint32_t nBlocks = (pm->nChunks + 3) / 4;
-  const size_t shmem = ((size_t)pm->patDict + pm->patExcLds + 8) * sizeof(PatEntry) + (size_t)pm->ldsWindow * sizeof(double);
+  const uint32_t nBlocks = pm->patNTiles;
+  const size_t shmem = ((size_t)pm->patDict + pm->patExcLds + 8) * sizeof(PatEntry) + (size_t)pm->patWindow * sizeof(double);
   if (!stop) stop = zero_flag();
   const uint32_t first = part == 2 ? pm->patInterior : 0u;
   const uint32_t count = part == 1 ? pm->patInterior : part == 2 ? nBlocks - pm->patInterior : nBlocks;
   const uint32_t pper  = g_scs_xcd ? (count + 7) / 8 : 0;
   const dim3 pgrid(g_scs_xcd ? pper * 8 : count), block(256);
-#define PAT_LAUNCH(DO, SK, HA)                                                                                   \
-  hipLaunchKernelGGL((spmv_scs64_pat<DO, SK, HA>), pgrid, block, shmem, stream, pm->tileHdrs, pm->jcodes, pm->rowBase, \
-      pm->classDict, pm->rowPats, pm->excRows, pm->tileSegs, x, y, pm->nr, pm->nChunks, first, count, pper,           \
+#define PAT_LAUNCH(CP, DO, SK, HA)                                                                                           \
+  hipLaunchKernelGGL((spmv_scs64_pat<CP, DO, SK, HA>), pgrid, block, shmem, stream, pm->tileHdrs, pm->jcodes, pm->rowBase, \
+      pm->classDict, pm->rowPats, pm->excRows, pm->patSegs, x, y, pm->nr, pm->nChunks, first, count, pper,               \
       pm->padCol, pm->patDict, pm->patExcLds, dotPartials, stop, hw)
-#define PAT_PICK(SK, HA)                \
-  do {                                  \
-    if (dot) PAT_LAUNCH(true, SK, HA);  \
-    else PAT_LAUNCH(false, SK, HA);     \
+#define PAT_PICK(CP, SK, HA)                \
+  do {                                      \
+    if (dot) PAT_LAUNCH(CP, true, SK, HA);  \
+    else PAT_LAUNCH(CP, false, SK, HA);     \
   } while (0)
-  if (skipPad) {
-    if (halo) PAT_PICK(true, true);
-    else PAT_PICK(true, false);
-  } else {
-    if (halo) PAT_PICK(false, true);
-    else PAT_PICK(false, false);
-  }
+#define PAT_PICK2(CP)                       \
+  do {                                      \
+    if (skipPad) {                          \
+      if (halo) PAT_PICK(CP, true, true);   \
+      else PAT_PICK(CP, true, false);       \
+    } else {                                \
+      if (halo) PAT_PICK(CP, false, true);  \
+      else PAT_PICK(CP, false, false);      \
+    }                                       \
+  } while (0)
+  if (pm->patCPT == 8) PAT_PICK2(8);
+  else PAT_PICK2(4);
+#undef PAT_PICK2
 #undef PAT_PICK
 #undef PAT_LAUNCH
   HIP_CHECK(hipGetLastError());

@@ -149,27 +149,31 @@ static void build_packed(sb_matrix* m, const double* hostVal, const uint32_t* ol
   m->usePacked = m->packedBytes <= 0.9 * (12.0 * m->nElems) ? 1 : 0;
 }
 
-// Level 3 of the compressed mirror: per tile (4 chunks = one workgroup) the contiguous
-// column ranges its rows touch, so the kernel can stage them in LDS (pack.hip.h).
-// Host arrays are the reference-layout ones (columns in ORIGINAL numbering).
-static void build_lds_windows(sb_matrix* m, const uint32_t* chunkPtr, const uint32_t* chunkLens,
-    const uint32_t* colInd, const double* val, const uint32_t* oldToNewPerm)
-{
-  if (m->packLevel < 1) return;
-  const char* env = getenv("SB_PACK");
-  if ((env ? atoi(env) : 3) < 3) return;
-  const uint32_t WMAX = 6144, MERGE_GAP = 8; // window <= 48 KiB of LDS per workgroup
-  const uint32_t nTiles = (m->nChunks + 3) / 4;
-  std::vector<uint32_t> segPtr(nTiles + 1, 0);
+// The x windows of tiles of `cpt` chunks: per tile the contiguous column ranges its rows touch (columns in the
+// DEVICE numbering, i.e. renumbered by the SCS permutation), ranges closer than MERGE_GAP merged, slot 0 reserved
+// for x[padCol].  Host arrays are the reference-layout ones (columns in ORIGINAL numbering).  ok = false: some
+// tile's window exceeds WMAX entries.
+struct TileWindows {
+  std::vector<uint32_t> segPtr;
   std::vector<TileSeg> segs;
-  std::vector<uint32_t> cols;
-  std::vector<uint64_t> bitmap;
   uint32_t maxWin = 0;
   uint64_t sumWin = 0, sumElems = 0;
+  bool ok = false;
+};
+static TileWindows compute_tile_windows(const sb_matrix* m, uint32_t cpt, const uint32_t* chunkPtr,
+    const uint32_t* chunkLens, const uint32_t* colInd, const double* val, const uint32_t* oldToNewPerm)
+{
+  const uint32_t WMAX = 6144, MERGE_GAP = 8; // window <= 48 KiB of LDS per workgroup
+  const uint32_t nTiles = (m->nChunks + cpt - 1) / cpt;
+  TileWindows W;
+  W.segPtr.assign(nTiles + 1, 0);
+  std::vector<TileSeg>& segs = W.segs;
+  std::vector<uint32_t> cols;
+  std::vector<uint64_t> bitmap;
   for (uint32_t t = 0; t < nTiles; t++) {
     cols.clear();
     uint32_t lo = 0xFFFFFFFFu, hi = 0;
-    for (uint32_t c = t * 4; c < std::min(t * 4 + 4, m->nChunks); c++) {
+    for (uint32_t c = t * cpt; c < std::min(t * cpt + cpt, m->nChunks); c++) {
       const size_t cp = chunkPtr[c];
       const size_t n  = (size_t)chunkLens[c] * 64;
       for (size_t e = 0; e < n; e++) {
@@ -182,16 +186,16 @@ static void build_lds_windows(sb_matrix* m, const uint32_t* chunkPtr, const uint
         lo = std::min(lo, col), hi = std::max(hi, col);
       }
     }
-    segPtr[t] = (uint32_t)segs.size();
+    W.segPtr[t] = (uint32_t)segs.size();
     if (cols.empty()) continue;
     // distinct columns in ascending order: bitmap when the span is modest, sort otherwise
     const uint64_t span = (uint64_t)hi - lo + 1;
     uint32_t win = 1; // slot 0
     auto emit = [&](uint32_t first, uint32_t last) {
-      TileSeg s;
-      s.col = first, s.len = last - first + 1, s.lds = win, s.pad_ = 0;
-      win += s.len;
-      segs.push_back(s);
+      TileSeg sg;
+      sg.col = first, sg.len = last - first + 1, sg.lds = win, sg.pad_ = 0;
+      win += sg.len;
+      segs.push_back(sg);
     };
     if (span <= (1u << 22)) {
       bitmap.assign((span + 63) / 64, 0ull);
@@ -218,12 +222,33 @@ static void build_lds_windows(sb_matrix* m, const uint32_t* chunkPtr, const uint
       }
       emit(first, last);
     }
-    if (win > WMAX) return; // some tile's window does not fit LDS: stay at level 1/2
-    maxWin = std::max(maxWin, win);
-    sumWin += win;
-    sumElems += cols.size();
+    if (win > WMAX) return W; // some tile's window does not fit LDS
+    W.maxWin = std::max(W.maxWin, win);
+    W.sumWin += win;
+    W.sumElems += cols.size();
   }
-  segPtr[nTiles] = (uint32_t)segs.size();
+  W.segPtr[nTiles] = (uint32_t)segs.size();
+  if (W.maxWin == 0) W.maxWin = 1;
+  if (segs.empty()) segs.push_back(TileSeg{ 0, 0, 0, 0 });
+  W.ok = true;
+  return W;
+}
+
+// Level 3 of the compressed mirror: per tile (4 chunks = one workgroup) the x window is staged in LDS
+// (pack.hip.h: spmv_scs64_lds).
+static void build_lds_windows(sb_matrix* m, const uint32_t* chunkPtr, const uint32_t* chunkLens,
+    const uint32_t* colInd, const double* val, const uint32_t* oldToNewPerm)
+{
+  if (m->packLevel < 1) return;
+  const char* env = getenv("SB_PACK");
+  if ((env ? atoi(env) : 3) < 3) return;
+  const uint32_t nTiles = (m->nChunks + 3) / 4;
+  TileWindows W = compute_tile_windows(m, 4, chunkPtr, chunkLens, colInd, val, oldToNewPerm);
+  if (!W.ok) return; // stay at level 1/2
+  std::vector<uint32_t>& segPtr = W.segPtr;
+  std::vector<TileSeg>& segs    = W.segs;
+  const uint32_t maxWin = W.maxWin;
+  const uint64_t sumWin = W.sumWin, sumElems = W.sumElems;
   // Staging pays only when a window entry is reused several times and the window is made
   // of long runs (coalesced copies).  Measured: 27-pt stencil reuse 4.6 / run ~510 ->
   // 1.15x faster than gathering through the cache; irregular FE-like matrix with 5 % far
@@ -235,9 +260,6 @@ static void build_lds_windows(sb_matrix* m, const uint32_t* chunkPtr, const uint
     const bool want    = force ? atoi(force) != 0 : (reuse >= 3.0 && run >= 32.0);
     if (!want) return;
   }
-  if (maxWin == 0) maxWin = 1;
-  TileSeg dummy = { 0, 0, 0, 0 };
-  if (segs.empty()) segs.push_back(dummy);
   m->tileSegPtr = (uint32_t*)upload(segPtr.data(), segPtr.size() * sizeof(uint32_t));
   m->tileSegs   = (TileSeg*)upload(segs.data(), segs.size() * sizeof(TileSeg));
   std::vector<PackMeta> meta(m->nChunks);
@@ -245,7 +267,7 @@ static void build_lds_windows(sb_matrix* m, const uint32_t* chunkPtr, const uint
   const uint64_t groups = meta.empty() ? 0 : (uint64_t)meta.back().grp + ((meta.back().info & 0x7FFFFFFFu) + 3u) / 4u;
   HIP_CHECK(hipMalloc(&m->pslots, (size_t)groups * 512 + 1024));
   hipLaunchKernelGGL(pack_slots_k, dim3(nTiles), dim3(256), 0, g.stream, m->chunkPtr, m->chunkLens, m->colInd,
-      m->val, m->pmeta, m->tileSegPtr, m->tileSegs, m->nChunks, m->padCol, m->pslots);
+      m->val, m->pmeta, m->tileSegPtr, m->tileSegs, m->nChunks, m->padCol, m->pslots, 4u);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(g.stream));
   m->ldsWindow = maxWin;
@@ -260,6 +282,10 @@ static void build_lds_windows(sb_matrix* m, const uint32_t* chunkPtr, const uint
 // LDS windows.  SB_PACK=4 stops at level 4 (every chunk per-lane).
 struct PatternPlan { // working set of build_patterns
   uint32_t nTiles = 0;
+  uint32_t cpt    = 4;           // chunks per tile of the pattern kernel (4: level 3's tiles; 8: own windows)
+  const uint32_t* slots = nullptr; // device: 16-bit window slots of every element for THIS tiling
+  std::vector<uint32_t> segPtr;  // the tiling's windows (host copies)
+  std::vector<TileSeg> segs;
   // level 4
   std::vector<std::vector<uint32_t>> classes; // sorted pair keys of every class
   std::vector<uint32_t> tileClass;
@@ -284,7 +310,7 @@ static bool pattern_classes(sb_matrix* m, PatternPlan& P)
   HIP_CHECK(hipMalloc(&m->rowBase, (size_t)m->nChunks * 64 * sizeof(uint16_t) + 16));
   HIP_CHECK(hipMalloc(&dCount, (size_t)nTiles * sizeof(uint32_t)));
   HIP_CHECK(hipMalloc(&dKeys, (size_t)nTiles * 256 * sizeof(uint32_t)));
-  hipLaunchKernelGGL(pat_collect_k, dim3(nTiles), dim3(256), 0, g.stream, m->pmeta, m->pslots, m->pcodes,
+  hipLaunchKernelGGL(pat_collect_k, dim3(nTiles), dim3(64 * P.cpt), 0, g.stream, m->pmeta, P.slots, m->pcodes,
       m->nChunks, m->rowBase, dCount, dKeys);
   HIP_CHECK(hipGetLastError());
   std::vector<uint32_t> count(nTiles), keys((size_t)nTiles * 256);
@@ -355,7 +381,7 @@ static void pattern_rows(sb_matrix* m, PatternPlan& P, const std::vector<uint32_
     return (uint32_t)__builtin_popcount(P.exc[2 * (size_t)c]) + (uint32_t)__builtin_popcount(P.exc[2 * (size_t)c + 1]);
   };
   for (uint32_t t = 0; t < P.nTiles; t++) {
-    const uint32_t c0 = t * 4, c1 = std::min(c0 + 4, m->nChunks);
+    const uint32_t c0 = t * P.cpt, c1 = std::min(c0 + P.cpt, m->nChunks);
     uint64_t tileExc = 0;
     bool tileOk      = wantRows;
     for (uint32_t c = c0; c < c1 && tileOk; c++) {
@@ -363,7 +389,7 @@ static void pattern_rows(sb_matrix* m, PatternPlan& P, const std::vector<uint32_
       if (len == 0 || n_exc(c) > PAT_EXC_MAX) continue; // this chunk will be L
       tileExc += (uint64_t)n_exc(c) * len;
     }
-    if (tileExc > PAT_EXC_LDS_MAX) tileOk = false;
+    if (tileExc > PAT_EXC_LDS_MAX * (P.cpt / 4)) tileOk = false;
     P.tileExcStart[t] = (uint32_t)P.excEntries;
     for (uint32_t c = c0; c < c1; c++) {
       const uint32_t len = P.meta[c].info & 0x7FFFFFFFu, ng = (len + 3u) / 4u, nExc = n_exc(c);
@@ -405,42 +431,45 @@ static void pattern_rows(sb_matrix* m, PatternPlan& P, const std::vector<uint32_
 
 // one header per tile: class, chunk positions / widths / row patterns, the first segments; tiles
 // whose window holds a halo column (>= nr) go last, so that the interior part of the product does
-// not have to wait for the halo exchange (loop_body).  Returns the number of segments.
+// not have to wait for the halo exchange (loop_body).  4-chunk tiles: one TileHdr (48 words); 8-chunk tiles: two
+// TileHdr halves interleaved word by word into 128 words (X: the tile-level fields + chunks 0-3, Y: the per-chunk
+// fields of chunks 4-7), which the kernel fetches as one 8-byte vector load.  Returns the number of segments.
 static size_t pattern_headers(sb_matrix* m, const PatternPlan& P)
 {
-  const uint32_t nTiles = P.nTiles;
-  std::vector<uint32_t> segPtr(nTiles + 1);
-  sb_d2h(segPtr.data(), m->tileSegPtr, segPtr.size() * sizeof(uint32_t));
+  const uint32_t nTiles = P.nTiles, cpt = P.cpt, LONG = cpt == 8 ? 4u : 3u;
+  const std::vector<uint32_t>& segPtr = P.segPtr;
+  const std::vector<TileSeg>& segs    = P.segs;
   const size_t nSegs = segPtr[nTiles];
-  std::vector<TileSeg> segs(std::max<size_t>(nSegs, 1));
-  if (nSegs) sb_d2h(segs.data(), m->tileSegs, nSegs * sizeof(TileSeg));
-  std::vector<TileHdr> hdrs(nTiles);
+  struct Pair { TileHdr x, y; };
+  std::vector<Pair> hdrs(nTiles);
   for (uint32_t t = 0; t < nTiles; t++) {
-    TileHdr& h = hdrs[t];
-    memset(&h, 0, sizeof h);
+    TileHdr& h = hdrs[t].x;
+    memset(&hdrs[t], 0, sizeof(Pair));
     h.tile = t;
     h.cls = P.tileClass[t], h.nseg = segPtr[t + 1] - segPtr[t], h.segPtr = segPtr[t], h.win = 1;
     h.excStart = P.tileExcStart[t], h.excCount = P.tileExcCount[t];
-    for (uint32_t w = 0; w < 4; w++) {
-      const uint32_t c = t * 4 + w;
+    for (uint32_t w = 0; w < cpt; w++) {
+      const uint32_t c = t * cpt + w;
       if (c >= m->nChunks) continue;
-      h.off[w] = P.chunkOff[c], h.len[w] = P.chunkFlags[c], h.rowPat[w] = P.chunkPat[c];
-      if (P.chunkFlags[c] & PAT_UNIFORM) h.exc[w][0] = P.exc[2 * (size_t)c], h.exc[w][1] = P.exc[2 * (size_t)c + 1];
+      TileHdr& hh = w < 4 ? hdrs[t].x : hdrs[t].y;
+      const uint32_t k = w & 3u;
+      hh.off[k] = P.chunkOff[c], hh.len[k] = P.chunkFlags[c], hh.rowPat[k] = P.chunkPat[c];
+      if (P.chunkFlags[c] & PAT_UNIFORM) hh.exc[k][0] = P.exc[2 * (size_t)c], hh.exc[k][1] = P.exc[2 * (size_t)c + 1];
     }
-    for (uint32_t s = 0; s < PAT_INLINE_SEGS; s++) h.seg[s][1] = 0xFFFFFFFFu;
+    for (uint32_t s2 = 0; s2 < PAT_INLINE_SEGS; s2++) h.seg[s2][1] = 0xFFFFFFFFu;
     h.winInline = 1;
-    // simple window: <= 6 segments which, longest first, are 3 x <= 768 and 3 x <= 256 entries
+    // simple window: <= 6 segments which, longest first, are 3 x <= 256 * LONG and 3 x <= 256 entries
     std::vector<TileSeg> ts(segs.begin() + segPtr[t], segs.begin() + segPtr[t] + h.nseg);
     std::stable_sort(ts.begin(), ts.end(), [](const TileSeg& a, const TileSeg& b) { return a.len > b.len; });
     bool simple = h.nseg <= PAT_INLINE_SEGS;
-    for (uint32_t s = 0; s < h.nseg && simple; s++) simple = ts[s].len <= (s < 3 ? 768u : 256u);
-    for (uint32_t s = 0; s < h.nseg; s++) {
-      const TileSeg& sg = simple ? ts[s] : segs[segPtr[t] + s]; // slot order unless simple
-      if (s < PAT_INLINE_SEGS) h.seg[s][0] = sg.col, h.seg[s][1] = sg.lds, h.seg[s][2] = sg.len;
+    for (uint32_t s2 = 0; s2 < h.nseg && simple; s2++) simple = ts[s2].len <= (s2 < 3 ? 256u * LONG : 256u);
+    for (uint32_t s2 = 0; s2 < h.nseg; s2++) {
+      const TileSeg& sg = simple ? ts[s2] : segs[segPtr[t] + s2]; // slot order unless simple
+      if (s2 < PAT_INLINE_SEGS) h.seg[s2][0] = sg.col, h.seg[s2][1] = sg.lds, h.seg[s2][2] = sg.len;
     }
-    for (uint32_t s = 0; s < h.nseg; s++) {
-      const TileSeg& sg = segs[segPtr[t] + s];
-      if (s < PAT_INLINE_SEGS) h.winInline = sg.lds + sg.len;
+    for (uint32_t s2 = 0; s2 < h.nseg; s2++) {
+      const TileSeg& sg = segs[segPtr[t] + s2];
+      if (s2 < PAT_INLINE_SEGS) h.winInline = sg.lds + sg.len;
       h.win = sg.lds + sg.len;
     }
     h.flags = simple ? PAT_SIMPLE_WINDOW : 0u;
@@ -454,32 +483,89 @@ static size_t pattern_headers(sb_matrix* m, const PatternPlan& P)
       }
       return false;
     };
-    for (TileHdr& h : hdrs)
-      if (touches_halo(h)) h.flags |= PAT_TOUCHES_HALO;
-    auto mid = std::stable_partition(hdrs.begin(), hdrs.end(), [&](const TileHdr& h) { return !(h.flags & PAT_TOUCHES_HALO); });
+    for (Pair& h : hdrs)
+      if (touches_halo(h.x)) h.x.flags |= PAT_TOUCHES_HALO;
+    auto mid = std::stable_partition(hdrs.begin(), hdrs.end(), [&](const Pair& h) { return !(h.x.flags & PAT_TOUCHES_HALO); });
     m->patInterior = (uint32_t)(mid - hdrs.begin());
   }
-  m->tileHdrs = (TileHdr*)upload(hdrs.data(), hdrs.size() * sizeof(TileHdr));
+  const uint32_t stride = cpt == 8 ? 128u : 48u;
+  std::vector<uint32_t> words((size_t)nTiles * stride + 128, 0u);
+  for (uint32_t t = 0; t < nTiles; t++) {
+    const uint32_t* wx = reinterpret_cast<const uint32_t*>(&hdrs[t].x);
+    const uint32_t* wy = reinterpret_cast<const uint32_t*>(&hdrs[t].y);
+    uint32_t* o        = words.data() + (size_t)t * stride;
+    if (cpt == 8)
+      for (uint32_t i = 0; i < 48; i++) o[2 * i] = wx[i], o[2 * i + 1] = wy[i];
+    else memcpy(o, wx, 48 * sizeof(uint32_t));
+  }
+  m->tileHdrs = (uint32_t*)upload(words.data(), words.size() * sizeof(uint32_t));
   if (getenv("SB_PACK_REPORT")) {
     size_t nSimple = 0;
-    for (const TileHdr& h : hdrs) nSimple += h.flags & PAT_SIMPLE_WINDOW;
-    fprintf(stderr, "sbhip pack: %u tiles (%u interior, %zu simple windows, max %u entries), %zu classes, %u/%u U chunks, "
+    for (const Pair& h : hdrs) nSimple += h.x.flags & PAT_SIMPLE_WINDOW;
+    fprintf(stderr, "sbhip pack: %u tiles of %u chunks (%u interior, %zu simple windows, max %u entries), %zu classes, %u/%u U chunks, "
                     "%zu row patterns (%zu entries), %llu exception entries (max %u per tile), %llu code words\n",
-        nTiles, m->patInterior, nSimple, m->ldsWindow, P.classes.size(), m->nUniformChunks, m->nChunks, P.nRowPats,
+        nTiles, cpt, m->patInterior, nSimple, m->patWindow, P.classes.size(), m->nUniformChunks, m->nChunks, P.nRowPats,
         P.rowPats.size(), (unsigned long long)P.excEntries, P.excLds, (unsigned long long)P.words);
   }
   return nSegs;
 }
 
-static void build_patterns(sb_matrix* m)
+// Chunks per tile of the pattern kernel: 8 (two chunks per wave: one header fetch, window staging and barrier for
+// twice the rows) where every 8-chunk window fits LDS, else 4.  SB_PAT_CPT=4 keeps level 3's tiles.
+static void build_patterns(sb_matrix* m, const uint32_t* chunkPtr, const uint32_t* chunkLens, const uint32_t* colInd,
+    const double* val, const uint32_t* oldToNewPerm, uint32_t forceCpt = 0)
 {
   if (m->usePacked != 2 || m->nDict <= 0) return;
   const char* env = getenv("SB_PACK");
   if ((env ? atoi(env) : 4) < 4) return;
   PatternPlan P;
-  P.nTiles = (m->nChunks + 3) / 4;
-  if (!pattern_classes(m, P)) { // the matrix stays at level 3
-    sb_free(m->rowBase), m->rowBase = nullptr;
+  uint32_t* slots8 = nullptr; // device: window slots for 8-chunk tiles (temporary)
+  {
+    const char* ec = getenv("SB_PAT_CPT");
+    P.cpt          = ec && atoi(ec) == 4 ? 4u : 8u;
+    if (m->nChunks <= 4 || forceCpt == 4) P.cpt = 4;
+  }
+  if (P.cpt == 8) {
+    TileWindows W = compute_tile_windows(m, 8, chunkPtr, chunkLens, colInd, val, oldToNewPerm);
+    if (!W.ok) P.cpt = 4;
+    else {
+      P.segPtr = std::move(W.segPtr), P.segs = std::move(W.segs);
+      m->patWindow = W.maxWin;
+      uint32_t* dSegPtr = (uint32_t*)upload(P.segPtr.data(), P.segPtr.size() * sizeof(uint32_t));
+      m->patSegs        = (TileSeg*)upload(P.segs.data(), P.segs.size() * sizeof(TileSeg));
+      std::vector<PackMeta> meta(m->nChunks);
+      sb_d2h(meta.data(), m->pmeta, meta.size() * sizeof(PackMeta));
+      const uint64_t groups = (uint64_t)meta.back().grp + ((meta.back().info & 0x7FFFFFFFu) + 3u) / 4u;
+      HIP_CHECK(hipMalloc(&slots8, (size_t)groups * 512 + 1024));
+      hipLaunchKernelGGL(pack_slots_k, dim3((m->nChunks + 3) / 4), dim3(256), 0, g.stream, m->chunkPtr, m->chunkLens,
+          m->colInd, m->val, m->pmeta, dSegPtr, m->patSegs, m->nChunks, m->padCol, slots8, 8u);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(g.stream));
+      sb_free(dSegPtr);
+      P.slots = slots8;
+    }
+  }
+  if (P.cpt == 4) { // level 3's tiles and windows
+    P.slots = m->pslots;
+    P.segPtr.resize((m->nChunks + 3) / 4 + 1);
+    sb_d2h(P.segPtr.data(), m->tileSegPtr, P.segPtr.size() * sizeof(uint32_t));
+    P.segs.resize(std::max<size_t>(P.segPtr.back(), 1));
+    if (P.segPtr.back()) sb_d2h(P.segs.data(), m->tileSegs, (size_t)P.segPtr.back() * sizeof(TileSeg));
+    m->patSegs = m->tileSegs, m->patWindow = m->ldsWindow;
+  }
+  m->patCPT   = P.cpt;
+  P.nTiles    = (m->nChunks + P.cpt - 1) / P.cpt;
+  m->patNTiles = P.nTiles;
+  auto give_up = [&]() { // the matrix stays at level 3
+    sb_free(slots8);
+    if (m->patSegs != m->tileSegs) sb_free(m->patSegs);
+    m->patSegs = nullptr;
+    sb_free(m->rowBase), sb_free(m->classDict), sb_free(m->tileClass);
+    m->rowBase = nullptr, m->classDict = nullptr, m->tileClass = nullptr;
+  };
+  if (!pattern_classes(m, P)) { // (more pairs than a class holds in some tile: try the smaller tiles before giving up)
+    give_up();
+    if (P.cpt == 8) build_patterns(m, chunkPtr, chunkLens, colInd, val, oldToNewPerm, 4);
     return;
   }
   // per-lane code words of every chunk (its L form), then the dominant sequence + odd lanes
@@ -492,9 +578,10 @@ static void build_patterns(sb_matrix* m)
   HIP_CHECK(hipMalloc(&lanes, (size_t)P.groups * 256 + 1024));
   HIP_CHECK(hipMalloc(&dDom, (size_t)P.groups * sizeof(uint32_t) + 16));
   HIP_CHECK(hipMalloc(&dExc, (size_t)m->nChunks * 2 * sizeof(uint32_t)));
-  hipLaunchKernelGGL(pat_encode_k, dim3(P.nTiles), dim3(256), 0, g.stream, m->pmeta, m->pslots, m->pcodes,
+  const uint32_t nBlocks4 = (m->nChunks + 3) / 4;
+  hipLaunchKernelGGL(pat_encode_k, dim3(P.nTiles), dim3(64 * P.cpt), 0, g.stream, m->pmeta, P.slots, m->pcodes,
       m->nChunks, m->rowBase, m->tileClass, dClassKeys, lanes);
-  hipLaunchKernelGGL(pat_dominant_k, dim3(P.nTiles), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dDom,
+  hipLaunchKernelGGL(pat_dominant_k, dim3(nBlocks4), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dDom,
       dExc);
   HIP_CHECK(hipGetLastError());
   std::vector<uint32_t> dom(P.groups ? P.groups : 1);
@@ -504,24 +591,24 @@ static void build_patterns(sb_matrix* m)
   sb_free(dDom), sb_free(dClassKeys);
   pattern_rows(m, P, dom, (env ? atoi(env) : 5) >= 5);
   if (P.words > 0xFFFFFFFFull || P.excEntries > 0xFFFFFFFFull) { // positions are 32-bit
-    sb_free(lanes), sb_free(dExc), sb_free(m->classDict), sb_free(m->tileClass), sb_free(m->rowBase);
-    m->classDict = nullptr, m->tileClass = nullptr, m->rowBase = nullptr;
+    sb_free(lanes), sb_free(dExc);
+    give_up();
     return;
   }
   // final form: L code words / expanded exception rows of the U chunks
   uint32_t* dOff   = (uint32_t*)upload(P.chunkOff.data(), P.chunkOff.size() * sizeof(uint32_t));
   uint32_t* dFlags = (uint32_t*)upload(P.chunkFlags.data(), P.chunkFlags.size() * sizeof(uint32_t));
-  const size_t streamBytes = (size_t)P.words * sizeof(uint32_t) + 1024;       // slack: clamped reads
-  const size_t excBytes    = ((size_t)P.excEntries + 520) * sizeof(PatEntry); // slack: 2 x 256 unconditional reads
+  const size_t streamBytes = (size_t)P.words * sizeof(uint32_t) + 1024;        // slack: clamped reads
+  const size_t excBytes    = ((size_t)P.excEntries + 1040) * sizeof(PatEntry); // slack: 4 x 256 unconditional reads
   HIP_CHECK(hipMalloc(&m->jcodes, streamBytes));
   HIP_CHECK(hipMalloc(&m->excRows, excBytes));
   HIP_CHECK(hipMemsetAsync(m->jcodes, 0, streamBytes, g.stream));
   HIP_CHECK(hipMemsetAsync(m->excRows, 0, excBytes, g.stream));
-  hipLaunchKernelGGL(pat_compact_k, dim3(P.nTiles), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dOff,
-      dFlags, dExc, m->rowBase, m->tileClass, m->classDict, m->jcodes, m->excRows);
+  hipLaunchKernelGGL(pat_compact_k, dim3(nBlocks4), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dOff,
+      dFlags, dExc, m->rowBase, m->tileClass, m->classDict, m->jcodes, m->excRows, P.cpt);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(g.stream));
-  sb_free(lanes), sb_free(dExc), sb_free(dOff), sb_free(dFlags);
+  sb_free(lanes), sb_free(dExc), sb_free(dOff), sb_free(dFlags), sb_free(slots8);
   m->rowPats     = (PatEntry*)upload(P.rowPats.data(), P.rowPats.size() * sizeof(PatEntry));
   m->nRowPats    = (uint32_t)P.nRowPats;
   m->nPatClasses = (uint32_t)P.classes.size();
@@ -529,12 +616,12 @@ static void build_patterns(sb_matrix* m)
   m->patExcLds   = P.excLds;
   const size_t nSegs = pattern_headers(m, P);
   m->patBytes = (double)P.words * 4.0 + 16.0 * (double)P.excEntries + 2.0 * 64.0 * m->nChunks + 16.0 * nSegs +
-                (double)sizeof(TileHdr) * P.nTiles + (P.anyL ? 4096.0 * P.classes.size() : 0.0) + 16.0 * P.rowPats.size();
+                (double)(P.cpt == 8 ? 384 : 192) * P.nTiles + (P.anyL ? 4096.0 * P.classes.size() : 0.0) + 16.0 * P.rowPats.size();
   // Default kernel: the pattern kernel once the matrix is more than one round of resident
-  // workgroups (8 per CU); below that everything is one dependent-latency chain and the
+  // workgroups (8 per CU, 4 chunks each); below that everything is one dependent-latency chain and the
   // level-3 kernel's is shorter (64^3: 46.7k vs 43.2k CG it/s; 96^3: 22.8k vs 26.3k).
   // sb_matrix_use_packed(m, 3) selects it regardless.
-  m->usePacked = P.nTiles > (uint32_t)g.prop.multiProcessorCount * 8u ? 3 : 2;
+  m->usePacked = (m->nChunks + 3) / 4 > (uint32_t)g.prop.multiProcessorCount * 8u ? 3 : 2;
 }
 
 sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, uint32_t nChunks,
@@ -583,7 +670,7 @@ sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, u
   }
   build_packed(m, val, oldToNewPerm);
   build_lds_windows(m, chunkPtr, chunkLens, colInd, val, oldToNewPerm);
-  build_patterns(m);
+  build_patterns(m, chunkPtr, chunkLens, colInd, val, oldToNewPerm);
   return m;
 }
 
@@ -652,6 +739,7 @@ void sb_matrix_free(sb_matrix* m)
   sb_free(m->rowPtr), sb_free(m->rowBlocks), sb_free(m->chunkPtr), sb_free(m->chunkLens);
   sb_free(m->oldToNew), sb_free(m->newToOld), sb_free(m->colInd), sb_free(m->val);
   sb_free(m->pmeta), sb_free(m->pidx), sb_free(m->pcodes), sb_free(m->pdict);
+  if (m->patSegs != m->tileSegs) sb_free(m->patSegs);
   sb_free(m->tileSegPtr), sb_free(m->tileSegs), sb_free(m->pslots);
   sb_free(m->rowBase), sb_free(m->tileClass), sb_free(m->jcodes), sb_free(m->classDict), sb_free(m->tileHdrs), sb_free(m->rowPats), sb_free(m->excRows);
   if (m->mirror) sb_matrix_free(m->mirror);
@@ -671,7 +759,11 @@ void sb_matrix_use_packed(sb_matrix* m, int mode)
 int sb_matrix_packed_mode(const sb_matrix* m) { return m->usePacked; }
 // the matrix whose pattern levels serve m: m itself (SCS) or its private mirror (CRS)
 static const sb_matrix* pat_of(const sb_matrix* m) { return m->fmt == 0 && m->mirror ? m->mirror : m; }
-uint32_t sb_matrix_lds_window(const sb_matrix* m) { return pat_of(m)->ldsWindow; }
+uint32_t sb_matrix_lds_window(const sb_matrix* m)
+{ // doubles per workgroup of the SELECTED kernel's window (the pattern kernel may use tiles of 8 chunks)
+  const sb_matrix* pm = pat_of(m);
+  return pm->usePacked == 3 && pm->patWindow ? pm->patWindow : pm->ldsWindow;
+}
 uint32_t sb_matrix_pattern_classes(const sb_matrix* m) { return pat_of(m)->nPatClasses; }
 uint32_t sb_matrix_row_patterns(const sb_matrix* m, uint32_t* uniformChunks)
 {
