@@ -291,6 +291,8 @@ def roofline_block(kernel, moved, alg, us, launches, traffic, traffic_src, traff
            "avg_launch_us": us, "launches_timed": launches}
     if traffic:
         blk["traffic_over_bytes"] = traffic / moved
+        if launches:  # the same fraction on the bytes the PMC counters saw (gathers that miss the caches included)
+            blk["frac_on_traffic"] = traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
     if traffic_note:
         blk["traffic_note"] = traffic_note
     return blk

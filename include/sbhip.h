@@ -163,7 +163,7 @@ int sb_comm_p2p_handle(unsigned char* handle_out);
 int sb_comm_p2p_open(const unsigned char* all_handles); /* NULL: this rank has no handle */
 int sb_comm_p2p_enabled(void);
 /* one line saying why the path is on or off (which rank, which call failed, what the self-test saw);
- * waits inside CG are bounded by SB_P2P_TIMEOUT_MS (default 30000), the set-up self-tests by 2 s */
+ * waits inside CG are bounded by SB_P2P_TIMEOUT_MS (default 30000), the set-up self-tests by 5 s */
 const char* sb_comm_p2p_reason(void);
 void sb_comm_finalize(void);
 int sb_comm_rank(void);

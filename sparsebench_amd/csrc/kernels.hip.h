@@ -593,7 +593,7 @@ struct P2PView {
 };
 // A wait is bounded so that a dead peer ends the run with a message instead of hanging the GPU; the bound
 // is generous (default 30 s inside CG, SB_P2P_TIMEOUT_MS) because a merely LATE peer (first-kernel load, OS
-// jitter) must not be fatal -- RCCL would simply wait.  The set-up self-tests use 2 s.
+// jitter) must not be fatal -- RCCL would simply wait.  The set-up self-tests use 5 s.
 constexpr long long P2P_TICKS_PER_MS = 100000ll;
 
 // every thread of the workgroup calls this with the same `mine`; returns the same sum in every thread
