@@ -29,6 +29,7 @@ def _free_port():
     ("crs", 64, 1, 16, 2, 100),
     ("scs", 4, 8, 8, 3, 40),        # generic-C kernel, odd rank count
     ("scs", 64, 1, 48, 3, 150),     # several tiles per rank, many exchanges: staging-area parity, flags, row patterns
+    ("scs", 64, 256, 128, 2, 20),   # BASELINE configs[3]'s brick (128^3 per rank, Sell-64-256), two ranks on the one GPU
 ])
 @pytest.mark.parametrize("p2p", ["1", "0"])
 def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax, p2p):
