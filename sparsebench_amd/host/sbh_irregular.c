@@ -209,7 +209,9 @@ void sbh_matrix_generate_irregular(GMatrix* m, Parameter* p, int rank, int size)
      * [0.69, 25.7]; r.r falls by ~1e-16 per 50 CG iterations and stays a normal number for > 600 */
     diag->val = 0x1p-4 + off;
   }
-  m->nr = (CG_UINT)nr, m->nc = (CG_UINT)totalNr; /* columns are global until commPartition */
+  /* nc = local rows, as the reference's generator and matrixConvertfromMM leave it: columns stay global
+   * until commPartition, which renumbers them and adds the externals (src/comm.c:616) */
+  m->nr = (CG_UINT)nr, m->nc = (CG_UINT)nr;
   m->startRow = (CG_UINT)first, m->stopRow = (CG_UINT)(first + nr - 1);
   m->totalNr  = (CG_UINT)totalNr;
   m->nnz      = (CG_UINT)total;

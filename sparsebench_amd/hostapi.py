@@ -56,6 +56,8 @@ def host():
     H.sbh_problem_rhs.argtypes = [vp, vp, vp]
     H.sbh_problem_free.argtypes = [vp]
     H.commSetExchange.argtypes = [vp]
+    H.MMMatrixRead.argtypes = [vp, C.c_char_p]
+    H.commDistributeMatrix.argtypes = [vp, vp, vp]
     H.sbh_exchange_rccl.restype = vp
     _host = H
     return H

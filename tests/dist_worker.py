@@ -23,6 +23,83 @@ from oracle import pyoracle as po  # noqa: E402
 from sparsebench_amd import hostapi  # noqa: E402
 
 
+class MME(C.Structure):
+    _fields_ = [("row", C.c_int), ("col", C.c_int), ("val", C.c_double)]
+
+
+class MMM(C.Structure):
+    _fields_ = [("count", C.c_size_t), ("nr", C.c_int), ("nnz", C.c_int), ("totalNr", C.c_int), ("totalNnz", C.c_int),
+                ("startRow", C.c_int), ("stopRow", C.c_int), ("entries", C.POINTER(MME))]
+
+
+class CommS(C.Structure):  # include/sparsebench/sparsebench.h: Comm
+    _fields_ = [("rank", C.c_int), ("size", C.c_int), ("logFile", C.c_void_p), ("externalCount", C.c_int),
+                ("totalSendCount", C.c_int), ("elementsToSend", C.c_void_p), ("indegree", C.c_int), ("outdegree", C.c_int),
+                ("sources", C.c_void_p), ("recvCounts", C.c_void_p), ("rdispls", C.c_void_p), ("destinations", C.c_void_p),
+                ("sendCounts", C.c_void_p), ("sdispls", C.c_void_p), ("sendBuffer", C.c_void_p), ("dev", C.c_void_p),
+                ("externalGlobal", C.c_void_p)]
+
+
+def distribute_case(H, rank, size):
+    """commDistributeMatrix with the REFERENCE's contract (src/main.c:63-70, src/comm.c:311-402): only the master has
+    read the file, the other ranks pass an uninitialised MMMatrix; every rank must end up with exactly the rows the
+    file rule gives it (src/comm.c:35-38), entries in file order, and the global counts."""
+    path = os.path.join(ROOT, "tests", "golden", "ref", "matrix_band_klein.mtx")
+    comm = CommS()
+    comm.rank, comm.size = rank, size
+    mm, loc = MMM(), MMM()
+    if rank == 0:
+        H.MMMatrixRead(C.byref(mm), path.encode())
+    else:  # garbage, as an uninitialised stack variable would be
+        C.memset(C.byref(mm), 0x5A, C.sizeof(mm))
+    H.commDistributeMatrix(C.byref(comm), C.byref(mm), C.byref(loc))
+    g = po.GMatrix.from_mtx(path, rank, size)  # the oracle's row slice of the same file
+    assert loc.nr == g.nr and loc.startRow == g.startRow and loc.stopRow == g.stopRow, (loc.nr, g.nr)
+    assert loc.totalNr == 100 and loc.totalNnz == 298 and loc.count == g.nnzTrue == loc.nnz
+    rows = np.repeat(np.arange(g.nr), np.diff(g.rowPtr.astype(np.int64))) + g.startRow
+    got = [(loc.entries[i].row, loc.entries[i].col, loc.entries[i].val) for i in range(loc.count)]
+    assert [e[0] for e in got] == rows.tolist()
+    assert [e[1] for e in got] == g.col.tolist() and [e[2] for e in got] == g.val.tolist()
+    dist.barrier()
+    if rank == 0:
+        print("DIST_OK distribute", size, flush=True)
+    dist.destroy_process_group()
+
+
+def irregular_case(H, rank, size):
+    """configs[4] stand-in on several ranks: generator slice -> commPartition (far couplings give every rank many
+    neighbours) -> plan and renumbered matrix equal to the oracle's partition of the one-rank matrix's row slices"""
+    n = 10
+    prob = hostapi.Problem("irregular", n, n, n, fmt="crs", rank=rank, size=size, upload=False)
+    locs = []
+    for r in range(size):  # the oracle partitions row slices of the ONE-rank matrix (global column ids)
+        one = hostapi.Problem("irregular", n, n, n, fmt="crs", rank=0, size=1, upload=False)
+        rp = one.array("rowPtr").astype(np.int64)
+        col, val = one.gm_entries()
+        nr = one.nr
+        base, extra = nr // size, nr % size
+        lo = r * base + min(r, extra)
+        hi = lo + base + (1 if r < extra else 0)
+        g = po.GMatrix.from_csr((rp[lo:hi + 1] - rp[lo]).astype(np.uint32), col[rp[lo]:rp[hi]], val[rp[lo]:rp[hi]], nc=nr)
+        g.s.startRow, g.s.stopRow, g.s.totalNr = lo, hi - 1, nr
+        locs.append(g)
+        one.free()
+    plans = po.Plans(locs)
+    mine, g = plans.plan(rank), locs[rank]
+    assert prob.nr == g.nr and prob.nc == g.nc, (prob.nc, g.nc)
+    col, val = prob.gm_entries()
+    assert np.array_equal(col, g.col) and np.array_equal(val, g.val)
+    for f in ("externalCount", "totalSendCount", "indegree", "outdegree"):
+        assert getattr(prob, f) == mine[f], f
+    for f in ("sources", "recvCounts", "rdispls", "destinations", "sendCounts", "sdispls", "elementsToSend", "externalGlobal"):
+        assert np.array_equal(prob.array(f), mine[f]), f
+    assert prob.indegree == size - 1  # far couplings: everybody talks to everybody
+    dist.barrier()
+    if rank == 0:
+        print("DIST_OK irregular", size, flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     dist.init_process_group("gloo")
     rank, size = dist.get_rank(), dist.get_world_size()
@@ -61,6 +138,10 @@ def main():
     H.commSetExchange(C.byref(xchg))
 
     case = sys.argv[1]
+    if case == "distribute":
+        return distribute_case(H, rank, size)
+    if case == "irregular":
+        return irregular_case(H, rank, size)
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "cg_hist_mpi.json")))
     if case == "hpcg":
         n = 16 if size <= 4 else 8
