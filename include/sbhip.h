@@ -100,6 +100,10 @@ uint32_t sb_matrix_pattern_classes(const sb_matrix* m); /* pattern tables built 
 /* mode 3, level 5: distinct shared row patterns; *uniformChunks = chunks stored as one row
  * pattern + exception lanes (the rest keep per-lane codes).  SB_PACK=4 builds none. */
 uint32_t sb_matrix_row_patterns(const sb_matrix* m, uint32_t* uniformChunks);
+/* mode 5, level 6: distinct masked row programs; *maskedChunks = chunks stored as one program + per-row base slots
+ * (every lane runs the program, each add under the mask of the lanes that have the entry).  0 if not built
+ * (SB_PACK=5 builds none; fewer than 98 % of the chunks qualifying: not kept). */
+uint32_t sb_matrix_row_programs(const sb_matrix* m, uint32_t* maskedChunks);
 /* bytes the selected SpMV kernel really moves per launch (stream + x + y) */
 double sb_matrix_stream_bytes(const sb_matrix* m);
 

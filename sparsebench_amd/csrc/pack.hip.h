@@ -477,7 +477,9 @@ __global__ __launch_bounds__(512) void pat_encode_k(const PackMeta* __restrict__
 // is full, stay in the per-lane form (L chunks).  Lossless, same order, same bits.
 constexpr uint32_t PAT_INLINE_SEGS = 6;
 constexpr uint32_t PAT_UNIFORM     = 0x80000000u; // TileHdr.len[] flag: dominant-pattern chunk
-constexpr uint32_t PAT_NOPAD       = 0x40000000u; // ... whose dominant pattern holds no padding
+constexpr uint32_t PAT_NOPAD       = 0x40000000u; // ... whose dominant pattern holds no padding (masked form: no masked lane)
+constexpr uint32_t PAT_HASPAD      = 0x20000000u; // masked form: some row of the chunk is shorter than the chunk (reference padding)
+constexpr uint32_t PAT_LEN_MASK    = 0x1FFFFFFFu;
 constexpr uint32_t PAT_EXC_MAX     = 8; // more exception lanes than this: L chunk (an exception
                                         // row costs 16 B per column, a per-lane row 1 B)
 
@@ -507,6 +509,9 @@ constexpr int PAT_STOP_LANE          = 48; // the lane that fetches the stop fla
 // of <= 256 (1 load): staged segment by segment, no per-entry search
 constexpr uint32_t PAT_SIMPLE_WINDOW = 1u;
 constexpr uint32_t PAT_TOUCHES_HALO  = 2u; // the window holds columns >= nr (entries of other ranks)
+// level 6, row-permuted matrices: the window is laid out in ORIGINAL column order and staged through a 16-bit
+// map (slot -> device column - base of the slot's block of 256; the 18 segment words hold the block bases)
+constexpr uint32_t PAT_MAPPED_WINDOW = 4u;
 
 // HALO instantiation of spmv_scs64_pat (several ranks, peer-mapped halo exchange, kernels.hip.h):
 // the neighbours' halo_push_k kernels store straight into this rank's staging area; instead of a
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(256) void pat_compact_k(const PackMeta* __restrict_
     const uint32_t lo = excMask[2 * (size_t)chunk], hi = excMask[2 * (size_t)chunk + 1];
     const bool isExc  = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
     const uint32_t ix = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-    if (isExc) {
+    if (isExc && excRows) { // (masked form: U chunks store nothing per lane)
       const PatEntry* cd   = classDict + (size_t)tileClass[chunk / cpt] * 256;
       const uint32_t base8 = (uint32_t)rowBase[(size_t)chunk * 64 + lane] << 3;
       for (uint32_t j = 0; j < len; j++) {
@@ -587,6 +592,79 @@ __global__ __launch_bounds__(256) void pat_compact_k(const PackMeta* __restrict_
     }
   } else {
     for (uint32_t g = 0; g < ng; g++) stream[(size_t)off + (size_t)g * 64 + lane] = c[(size_t)g * 64];
+  }
+}
+
+// ---- level 6: masked row programs --------------------------------------------------------------
+// Round-2 measurements of the level-5 kernel: ~1270 VALU clocks per chunk against ~330 for the
+// arithmetic, most of the difference spent on the odd lanes -- nearly every chunk has one or two (rows next to
+// a grid boundary), so nearly every chunk runs the divergent "override from LDS" branch for every column, and
+// their expanded entries cost registers (16 VGPRs of prefetch) and LDS (occupancy).  But an odd row of a
+// structured matrix is almost always a SUB-SEQUENCE of a longer row of the same tile, shifted: the stencil row
+// at x = 0 is the interior row without its x-1 entries.  So a chunk is stored as a ROW PROGRAM
+//     entry j = (value, window offset relative to the lane's base slot, 64-bit mask of the lanes that HAVE it)
+// shared by all chunks with the same program, and a per-row 16-bit base slot chosen so that the row's own
+// entries line up with the program's.  Every lane executes every entry; the add of entry j runs under
+// EXEC = mask j (two scalar moves), so a lane that lacks the entry keeps its sum: no divergence, no per-lane
+// data, no exception area in LDS.  The order of a row's additions is unchanged (a sub-sequence of the
+// program, left to right), so results are the reference's bit for bit.  Reference padding (Sell-C-sigma rows
+// shorter than their chunk add 0.0 * x[padCol] per missing column, src/matrix-SCS.c:151-155 / :208-227) is
+// one masked add of 0.0 * x[padCol] behind the program: adding it once or several times gives the same bits
+// (s + 0.0 = s for every finite or infinite s that an accumulation starting from +0.0 can hold; NaN stays NaN).
+// Chunks whose rows do not fit any program of their tile keep the per-lane code words (L chunks).
+// A program is stored in blocks of 8 entries, structure-of-arrays, so that a batch of 8 entries is three scalar
+// loads (values, masks, offsets); entries behind the program's end have mask 0.
+struct ProgBlock {
+  double v[8];
+  unsigned long long mask[8]; // lanes that have the entry
+  uint32_t off8[8];           // byte offset of the entry's x in the window, relative to 8 * the row's base slot
+  uint32_t pad_[8];
+};
+static_assert(sizeof(ProgBlock) == 192, "blocks stay 64-byte aligned");
+typedef double f64x8 __attribute__((ext_vector_type(8)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));
+typedef unsigned long long u64x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+
+// acc += prod in the lanes of `mask` only
+__device__ __forceinline__ void masked_add(double& acc, double prod, unsigned long long mask)
+{
+  asm volatile("s_mov_b64 exec, %2\n\tv_add_f64 %0, %0, %1\n\ts_mov_b64 exec, -1" : "+v"(acc) : "v"(prod), "s"(mask));
+}
+
+// the first N (8 or 4) entries of a program block: entry loads (scalar), x reads (LDS), then products and adds
+template <int N, bool MASK>
+__device__ __forceinline__ void prog_batch(const ProgBlock* __restrict__ blk, uint32_t base8x, const char* ldsBytes,
+    double& acc)
+{
+  double v[N], xs[N];
+  unsigned long long mk[N];
+  uint32_t o[N];
+  if (N == 8) { // uniform addresses: s_load_dwordx16 / x16 / x8
+    const f64x8 vv = *reinterpret_cast<const f64x8*>(blk->v);
+    const u32x8 oo = *reinterpret_cast<const u32x8*>(blk->off8);
+#pragma unroll
+    for (int q = 0; q < N; q++) v[q] = vv[q], o[q] = oo[q];
+    if (MASK) {
+      const u64x8 mm = *reinterpret_cast<const u64x8*>(blk->mask);
+#pragma unroll
+      for (int q = 0; q < N; q++) mk[q] = mm[q];
+    }
+  } else {
+    const f64x4 vv = *reinterpret_cast<const f64x4*>(blk->v);
+    const u32x4 oo = *reinterpret_cast<const u32x4*>(blk->off8);
+    const u64x4 mm = *reinterpret_cast<const u64x4*>(blk->mask);
+#pragma unroll
+    for (int q = 0; q < N; q++) v[q] = vv[q], o[q] = oo[q], mk[q] = mm[q];
+  }
+#pragma unroll
+  for (int q = 0; q < N; q++) xs[q] = *reinterpret_cast<const double*>(ldsBytes + (base8x + o[q]));
+#pragma unroll
+  for (int q = 0; q < N; q++) {
+    const double prod = v[q] * xs[q];
+    if (MASK) masked_add(acc, prod, mk[q]);
+    else acc = acc + prod;
   }
 }
 
@@ -604,11 +682,13 @@ __global__ __launch_bounds__(256) void pat_compact_k(const PackMeta* __restrict_
 // DESIGN 4.2), the window holds 25 % fewer entries per row, and a CU gets through its tiles in fewer rounds.  The
 // 8-chunk header is two 48-word halves interleaved word by word (X: the tile-level fields and chunks 0-3, Y: the
 // per-chunk fields of chunks 4-7 in the same positions), fetched as ONE 8-byte vector load.
-template <int CPT, bool DOT, bool SKIPPAD, bool HALO>
+// MASKED: the level-6 form (row programs in `progs`, signed row bases, no exception entries; rowPats / excRows unused).
+template <int CPT, bool DOT, bool SKIPPAD, bool HALO, bool MASKED>
 __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict__ hdrWords,
     const uint32_t* __restrict__ stream, const uint16_t* __restrict__ rowBase,
     const PatEntry* __restrict__ classDict, const PatEntry* __restrict__ rowPats,
-    const PatEntry* __restrict__ excRows, const TileSeg* __restrict__ segs,
+    const PatEntry* __restrict__ excRows, const ProgBlock* __restrict__ progs, const uint16_t* __restrict__ slotMap,
+    uint32_t mapStride, const TileSeg* __restrict__ segs,
     const double* __restrict__ x, double* __restrict__ y, uint32_t nr, uint32_t nChunks,
     uint32_t firstHdr, uint32_t nHdrs, uint32_t blocksPerXcd, uint32_t padCol, uint32_t dictEntries,
     uint32_t excLds, double* __restrict__ dotPartials, const int* __restrict__ stop, HaloWait hw)
@@ -621,7 +701,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
   constexpr int PF   = 8;                // code groups prefetched (32 columns); wider chunks stream the rest
   constexpr int LONG = CPT == 8 ? 4 : 3; // loads per thread for each of the three long segments of a simple window
   constexpr int WB   = 3 * LONG + 3;     // window entries per thread in the first pass
-  constexpr int EXL  = CPT / 2;          // unconditional exception loads per thread (256 entries each)
+  constexpr int EXL  = MASKED ? 0 : CPT / 2; // unconditional exception loads per thread (256 entries each)
   // A launch covers headers [firstHdr, firstHdr + nHdrs).  Headers are stored with the tiles
   // that touch no halo column first, so that on several ranks the interior part of the
   // product can run while the halo is still in flight (one launch for each part).
@@ -680,13 +760,14 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
     row[c]   = chunk[c] * 64u + lane;
     off[c]   = cfield(c, 4 + (int)wv);
     lenf[c]  = cfield(c, 8 + (int)wv);
-    base[c]  = (int32_t)rowBase[chunk[c] < nChunks ? row[c] : 0u];
+    base[c]  = MASKED ? (int32_t)reinterpret_cast<const int16_t*>(rowBase)[chunk[c] < nChunks ? row[c] : 0u]
+                      : (int32_t)rowBase[chunk[c] < nChunks ? row[c] : 0u];
     xrow[c]  = DOT ? x[min(row[c], nr - 1u)] : 0.0;
   }
   // (per-lane code words are prefetched for the wave's FIRST chunk only; a second L chunk fetches its own later:
   //  matrices that come here in the 8-chunk form are made of U chunks almost everywhere)
   const bool uni0       = (lenf[0] & PAT_UNIFORM) != 0u; // wave-uniform
-  const uint32_t len0   = lenf[0] & ~(PAT_UNIFORM | PAT_NOPAD), ng0 = (len0 + 3u) >> 2;
+  const uint32_t len0   = lenf[0] & PAT_LEN_MASK, ng0 = (len0 + 3u) >> 2;
   const uint32_t gLast0 = ng0 ? ng0 - 1u : 0u;
   uint32_t cw[PF];
 #pragma unroll
@@ -698,12 +779,20 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
   }
   PatEntry mine = { 0.0, 0u, 0u };
   if (dictEntries) mine = classDict[(size_t)cls * 256 + threadIdx.x];
-  PatEntry ex[EXL];
+  PatEntry ex[EXL + 1];
 #pragma unroll
   for (int q = 0; q < EXL; q++) ex[q] = excRows[(size_t)excStart + (uint32_t)q * 256u + threadIdx.x]; // (slack behind excRows)
   const double xpad = x[padCol]; // slot 0: what padding multiplies (src/matrix-SCS.c:151-155)
   double t[WB];
-  if (simple) { // segment by segment: entry i of segment s -> slot first_s + i
+  const bool mappedWin = MASKED && (flags & PAT_MAPPED_WINDOW) != 0u; // uniform per workgroup
+  if (mappedWin) { // slot by slot through the map (its address depends on the tile number only: same round trip as the header)
+    const uint16_t* mp = slotMap + (size_t)tile * mapStride + threadIdx.x;
+    uint32_t d[WB];
+#pragma unroll
+    for (int k = 0; k < WB; k++) d[k] = mp[min((uint32_t)k * 256u, mapStride - 256u)];
+#pragma unroll
+    for (int k = 0; k < WB; k++) t[k] = xcol(field(12 + min(k, 17)) + d[k]);
+  } else if (simple) { // segment by segment: entry i of segment s -> slot first_s + i
 #pragma unroll
     for (int sI = 0; sI < 3; sI++) {
       const uint32_t sc = field(12 + 3 * sI), sn = field(12 + 3 * sI + 2);
@@ -739,7 +828,16 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
   for (int q = 0; q < EXL; q++) asm volatile("" ::"v"(ex[q].v), "v"(ex[q].off8));
   asm volatile("" ::"v"(xpad), "v"(mine.v), "v"(mine.off8), "v"(mine.m));
   if (tile0 >= nHdrs || stopped) return; // uniform per workgroup
-  if (simple) {
+  if (mappedWin) {
+    const uint32_t win = field(3);
+#pragma unroll
+    for (int k = 0; k < WB; k++) {
+      const uint32_t slot = (uint32_t)k * 256u + threadIdx.x;
+      if (slot < win) sx[slot] = t[k];
+    }
+    if (threadIdx.x == 0) sx[0] = xpad;
+    if (win > 256u * WB) __builtin_trap(); // (the host builds no such window)
+  } else if (simple) {
     if (threadIdx.x == 0) sx[0] = xpad;
 #pragma unroll
     for (int sI = 0; sI < 3; sI++) {
@@ -784,10 +882,11 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
     const uint32_t i = (uint32_t)q * 256u + threadIdx.x;
     if (i < excCount) se[i] = PatEntry{ ex[q].v, ex[q].off8 + sxOff, ex[q].m };
   }
-  for (uint32_t i = (uint32_t)EXL * 256u + threadIdx.x; i < excCount; i += 256u) {
-    const PatEntry e = excRows[(size_t)excStart + i];
-    se[i]            = PatEntry{ e.v, e.off8 + sxOff, e.m };
-  }
+  if (!MASKED)
+    for (uint32_t i = (uint32_t)EXL * 256u + threadIdx.x; i < excCount; i += 256u) {
+      const PatEntry e = excRows[(size_t)excStart + i];
+      se[i]            = PatEntry{ e.v, e.off8 + sxOff, e.m };
+    }
   if (dictEntries) sd[threadIdx.x] = PatEntry{ mine.v, mine.off8 + sxOff, mine.m };
   __syncthreads();
   // An element costs: entry -> byte offset of its x in the window -> x -> multiply -> add.
@@ -799,12 +898,33 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
 #pragma unroll
   for (int c = 0; c < CW; c++) {
     if (chunk[c] >= nChunks) continue; // wave-uniform; inactive waves only helped staging
-    const uint32_t len = lenf[c] & ~(PAT_UNIFORM | PAT_NOPAD), ng = (len + 3u) >> 2;
+    const uint32_t len = lenf[c] & PAT_LEN_MASK, ng = (len + 3u) >> 2;
     const bool uni     = (lenf[c] & PAT_UNIFORM) != 0u; // wave-uniform
     double acc           = 0.0;
     const uint32_t base8 = (uint32_t)base[c] << 3;
     const uint32_t base8x = base8 + sxOff;
-    if (uni) {
+    if (MASKED && uni) {
+      // the chunk's row program out of scalar registers; every lane runs every entry, the adds under the entry's mask
+      const ProgBlock* pg  = progs + cfield(c, 32 + (int)wv);
+      const bool nomask    = (lenf[c] & PAT_NOPAD) != 0u; // wave-uniform: every lane has every entry
+      const char* ldsBytes = reinterpret_cast<const char*>(lds);
+      uint32_t j0          = 0;
+      // (not unrolled: a second batch in flight costs 24-40 scalar and 24 vector registers, i.e. occupancy)
+      if (nomask) {
+#pragma unroll 1
+        for (; j0 + 8u <= len; j0 += 8u) prog_batch<8, false>(pg + (j0 >> 3), base8x, ldsBytes, acc);
+      } else {
+#pragma unroll 1
+        for (; j0 + 8u <= len; j0 += 8u) prog_batch<8, true>(pg + (j0 >> 3), base8x, ldsBytes, acc);
+      }
+      if (j0 + 4u < len) prog_batch<8, true>(pg + (j0 >> 3), base8x, ldsBytes, acc); // 5..7 entries left (the rest: mask 0)
+      else if (j0 < len) prog_batch<4, true>(pg + (j0 >> 3), base8x, ldsBytes, acc); // 1..4
+      if (!SKIPPAD && (lenf[c] & PAT_HASPAD)) { // the reference's padding terms; lanes: the header's exc words
+        const unsigned long long padMask =
+            (unsigned long long)cfield(c, 36 + 2 * (int)wv) | ((unsigned long long)cfield(c, 37 + 2 * (int)wv) << 32);
+        masked_add(acc, 0.0 * xpad, padMask);
+      }
+    } else if (uni) {
       // dominant lanes: entries of the row pattern from scalar registers (s_load through the
       // scalar cache); exception lanes: their own ready-made entries from LDS.  Two groups
       // (8 columns) at a time, so that 8 entry loads / 8 x reads are in flight together.

@@ -208,6 +208,18 @@ struct sb_matrix {
   // the pattern kernel's tiles: patCPT = 4 or 8 chunks, with their own windows when that differs from level 3's 4
   uint32_t patCPT = 4, patNTiles = 0, patWindow = 0;
   TileSeg* patSegs = nullptr; // == tileSegs when patCPT == 4
+  // level 6: the masked form of the same tiles (row programs; usePacked == 5)
+  uint32_t* mHdrs    = nullptr; // TileHdr words as tileHdrs; rowPat[] = first block of the chunk's program, exc[] = its padded lanes
+  uint32_t* mStream  = nullptr; // code words of its L chunks
+  int16_t* mRowBase  = nullptr; // per row: base slot that lines the row up with its chunk's program (may be < 0)
+  ProgBlock* mProgs  = nullptr;
+  uint32_t mDict = 0, nProgs = 0, nMaskedChunks = 0;
+  PatEntry* mClassDict = nullptr; // its class tables, windows and segments: the level-5 form's, or its own
+  TileSeg* mSegs       = nullptr; // (mOwnsTables) when the windows are laid out in original column order
+  uint16_t* mSlotMap   = nullptr; // ... then: [tile][mMapStride] slot -> device column - the 256-slot block's base
+  uint32_t mWindow = 0, mMapStride = 0;
+  bool mOwnsTables = false;
+  double mBytes  = 0.0;
   // CRS: a private Sell-64-1 mirror carrying only the pattern levels (SKIPPAD kernel); usePacked
   // 3 = product through the mirror, 0 = native CRS kernel
   sb_matrix* mirror = nullptr;

@@ -11,14 +11,14 @@ static int g_scs_xcd    = 1;
 // part: 0 the whole product; 1 / 2 its interior / halo-touching tiles (spmv_can_split only)
 static bool spmv_uses_patterns(const sb_matrix* m)
 {
-  return m->usePacked == 3 && (m->fmt == 0 ? m->mirror != nullptr : m->C == 64);
+  return (m->usePacked == 3 || m->usePacked == 5) && (m->fmt == 0 ? m->mirror != nullptr : m->C == 64);
 }
 static bool spmv_can_split(const sb_matrix* m)
 {
   const sb_matrix* pm = pat_of(m);
   return spmv_uses_patterns(m) && pm->patInterior > 0 && pm->patInterior < pm->patNTiles;
 }
-static void launch_pat(const sb_matrix* pm, bool skipPad, const double* x, double* y, double* dotPartials,
+static void launch_pat(const sb_matrix* pm, bool skipPad, bool masked, const double* x, double* y, double* dotPartials,
     const int* stop, int part, hipStream_t stream, const HaloWait* halo);
 
 // halo != NULL (pattern kernel only): the halo-touching tiles wait for the neighbours' pushes themselves
@@ -29,7 +29,7 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
   if (m->nr == 0) return;
   if (part != 0 && !spmv_can_split(m)) SB_FATAL("this SpMV kernel cannot be launched in parts");
   if (m->fmt == 0 && spmv_uses_patterns(m)) {
-    launch_pat(m->mirror, true, x, y, dotPartials, stop, part, stream ? stream : g.stream, halo);
+    launch_pat(m->mirror, true, m->usePacked == 5, x, y, dotPartials, stop, part, stream ? stream : g.stream, halo);
   } else if (m->fmt == 0) {
     if (dot) SB_FATAL("the native CRS kernel has no fused dot (its row blocks are not aligned to the 64-row groups of "
                       "the canonical dot; a kernel that is was measured slower, kernels.hip.h): sbhip_cg adds a dot pass");
@@ -48,8 +48,8 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
     const uint32_t nBlocks = (m->nChunks + 3) / 4;
     const uint32_t per     = g_scs_xcd ? (nBlocks + 7) / 8 : 0;
     dim3 grid(g_scs_xcd ? per * 8 : nBlocks), block(256);
-    if (m->usePacked == 3) {
-      launch_pat(m, false, x, y, dotPartials, stop, part, stream ? stream : g.stream, halo);
+    if (m->usePacked == 3 || m->usePacked == 5) {
+      launch_pat(m, false, m->usePacked == 5, x, y, dotPartials, stop, part, stream ? stream : g.stream, halo);
     } else if (m->usePacked == 2) {
       const size_t shmem = (256 + (size_t)m->ldsWindow) * sizeof(double);
 #define LDS_LAUNCH(DI, DO)                                                                                   \
@@ -103,41 +103,53 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
   HIP_CHECK(hipGetLastError());
 }
 
-static void launch_pat(const sb_matrix* pm, bool skipPad, const double* x, double* y, double* dotPartials,
+// masked: the level-6 form of the same tiles (row programs, pack.hip.h)
+static void launch_pat(const sb_matrix* pm, bool skipPad, bool masked, const double* x, double* y, double* dotPartials,
     const int* stop, int part, hipStream_t stream, const HaloWait* halo)
 {
   HaloWait hw;
   memset(&hw, 0, sizeof hw);
   if (halo) hw = *halo;
+  if (masked && !pm->mHdrs) SB_FATAL("the matrix has no masked row programs");
   const bool dot         = dotPartials != nullptr;
   const uint32_t nBlocks = pm->patNTiles;
-  const size_t shmem = ((size_t)pm->patDict + pm->patExcLds + 8) * sizeof(PatEntry) + (size_t)pm->patWindow * sizeof(double);
+  const uint32_t dictE = masked ? pm->mDict : pm->patDict, excE = masked ? 0u : pm->patExcLds;
+  const size_t shmem = ((size_t)dictE + excE + 8) * sizeof(PatEntry) + (size_t)(masked ? pm->mWindow : pm->patWindow) * sizeof(double);
   if (!stop) stop = zero_flag();
   const uint32_t first = part == 2 ? pm->patInterior : 0u;
   const uint32_t count = part == 1 ? pm->patInterior : part == 2 ? nBlocks - pm->patInterior : nBlocks;
   const uint32_t pper  = g_scs_xcd ? (count + 7) / 8 : 0;
   const dim3 pgrid(g_scs_xcd ? pper * 8 : count), block(256);
-#define PAT_LAUNCH(CP, DO, SK, HA)                                                                                           \
-  hipLaunchKernelGGL((spmv_scs64_pat<CP, DO, SK, HA>), pgrid, block, shmem, stream, pm->tileHdrs, pm->jcodes, pm->rowBase, \
-      pm->classDict, pm->rowPats, pm->excRows, pm->patSegs, x, y, pm->nr, pm->nChunks, first, count, pper,               \
-      pm->padCol, pm->patDict, pm->patExcLds, dotPartials, stop, hw)
-#define PAT_PICK(CP, SK, HA)                \
-  do {                                      \
-    if (dot) PAT_LAUNCH(CP, true, SK, HA);  \
-    else PAT_LAUNCH(CP, false, SK, HA);     \
+  const uint32_t* hdrs   = masked ? pm->mHdrs : pm->tileHdrs;
+  const uint32_t* codes  = masked ? pm->mStream : pm->jcodes;
+  const uint16_t* rbase  = masked ? reinterpret_cast<const uint16_t*>(pm->mRowBase) : pm->rowBase;
+#define PAT_LAUNCH(CP, DO, SK, HA, MA)                                                                                     \
+  hipLaunchKernelGGL((spmv_scs64_pat<CP, DO, SK, HA, MA>), pgrid, block, shmem, stream, hdrs, codes, rbase,                \
+      masked ? pm->mClassDict : pm->classDict, pm->rowPats, pm->excRows, pm->mProgs, pm->mSlotMap, pm->mMapStride,           \
+      masked ? pm->mSegs : pm->patSegs, x, y, pm->nr, pm->nChunks, first, count, pper, pm->padCol, dictE, excE, dotPartials, \
+      stop, hw)
+#define PAT_PICK(CP, SK, HA, MA)                \
+  do {                                          \
+    if (dot) PAT_LAUNCH(CP, true, SK, HA, MA);  \
+    else PAT_LAUNCH(CP, false, SK, HA, MA);     \
   } while (0)
-#define PAT_PICK2(CP)                       \
-  do {                                      \
-    if (skipPad) {                          \
-      if (halo) PAT_PICK(CP, true, true);   \
-      else PAT_PICK(CP, true, false);       \
-    } else {                                \
-      if (halo) PAT_PICK(CP, false, true);  \
-      else PAT_PICK(CP, false, false);      \
-    }                                       \
+#define PAT_PICK2(CP, MA)                       \
+  do {                                          \
+    if (skipPad) {                              \
+      if (halo) PAT_PICK(CP, true, true, MA);   \
+      else PAT_PICK(CP, true, false, MA);       \
+    } else {                                    \
+      if (halo) PAT_PICK(CP, false, true, MA);  \
+      else PAT_PICK(CP, false, false, MA);      \
+    }                                           \
   } while (0)
-  if (pm->patCPT == 8) PAT_PICK2(8);
-  else PAT_PICK2(4);
+  if (pm->patCPT == 8) {
+    if (masked) PAT_PICK2(8, true);
+    else PAT_PICK2(8, false);
+  } else {
+    if (masked) PAT_PICK2(4, true);
+    else PAT_PICK2(4, false);
+  }
 #undef PAT_PICK2
 #undef PAT_PICK
 #undef PAT_LAUNCH

@@ -161,7 +161,8 @@ struct TileWindows {
   bool ok = false;
 };
 static TileWindows compute_tile_windows(const sb_matrix* m, uint32_t cpt, const uint32_t* chunkPtr,
-    const uint32_t* chunkLens, const uint32_t* colInd, const double* val, const uint32_t* oldToNewPerm)
+    const uint32_t* chunkLens, const uint32_t* colInd, const double* val, const uint32_t* oldToNewPerm,
+    bool original = false) // original: windows in the ORIGINAL column numbering (level 6 of permuted matrices)
 {
   const uint32_t WMAX = 6144, MERGE_GAP = 8; // window <= 48 KiB of LDS per workgroup
   const uint32_t nTiles = (m->nChunks + cpt - 1) / cpt;
@@ -181,7 +182,7 @@ static TileWindows compute_tile_windows(const sb_matrix* m, uint32_t cpt, const 
         unsigned long long bits;
         memcpy(&bits, val + cp + e, 8);
         if (col == 0 && bits == 0) continue; // padding (or an explicit 0.0 at column 0): slot 0
-        if (m->permuted && col < m->nr) col = oldToNewPerm[col];
+        if (!original && m->permuted && col < m->nr) col = oldToNewPerm[col];
         cols.push_back(col);
         lo = std::min(lo, col), hi = std::max(hi, col);
       }
@@ -300,6 +301,20 @@ struct PatternPlan { // working set of build_patterns
   uint64_t words = 0, excEntries = 0; // L code words / U exception entries in total
   uint32_t excLds = 0;                // most exception entries of one tile
   bool anyL       = false;
+  // device side of the analysis (owned by whoever keeps the form)
+  uint16_t* dRowBase   = nullptr; // per row: window slot of its first element
+  uint32_t* dTileClass = nullptr;
+  PatEntry* dClassDict = nullptr;
+  uint32_t* dLanes     = nullptr; // per-lane code words of every chunk (temporary)
+  uint32_t* dExc       = nullptr; // [chunk][2] exception-lane mask (temporary)
+  std::vector<uint32_t> dom;      // dominant code words per group
+  // level 6 with the window in ORIGINAL column order (sigma > 1): slot -> device column
+  bool mapped = false;
+  uint32_t mapStride = 0;              // 16-bit map entries per tile (a multiple of 256)
+  std::vector<uint16_t> slotMap;       // [tile][mapStride]: device column - blockBase[slot / 256]
+  std::vector<uint32_t> blockBase;     // [tile][18]
+  void free_temporaries() { sb_free(dLanes), sb_free(dExc), dLanes = nullptr, dExc = nullptr; }
+  void free_tables() { sb_free(dRowBase), sb_free(dTileClass), sb_free(dClassDict), dRowBase = nullptr, dTileClass = nullptr, dClassDict = nullptr; }
 };
 
 // pairs of every tile (device) -> classes of <= PAT_MAX pairs -> class tables; false: level 3 stays
@@ -307,11 +322,11 @@ static bool pattern_classes(sb_matrix* m, PatternPlan& P)
 {
   const uint32_t nTiles = P.nTiles;
   uint32_t *dCount = nullptr, *dKeys = nullptr;
-  HIP_CHECK(hipMalloc(&m->rowBase, (size_t)m->nChunks * 64 * sizeof(uint16_t) + 16));
+  HIP_CHECK(hipMalloc(&P.dRowBase, (size_t)m->nChunks * 64 * sizeof(uint16_t) + 16));
   HIP_CHECK(hipMalloc(&dCount, (size_t)nTiles * sizeof(uint32_t)));
   HIP_CHECK(hipMalloc(&dKeys, (size_t)nTiles * 256 * sizeof(uint32_t)));
   hipLaunchKernelGGL(pat_collect_k, dim3(nTiles), dim3(64 * P.cpt), 0, g.stream, m->pmeta, P.slots, m->pcodes,
-      m->nChunks, m->rowBase, dCount, dKeys);
+      m->nChunks, P.dRowBase, dCount, dKeys);
   HIP_CHECK(hipGetLastError());
   std::vector<uint32_t> count(nTiles), keys((size_t)nTiles * 256);
   sb_d2h(count.data(), dCount, count.size() * sizeof(uint32_t));
@@ -350,7 +365,7 @@ static bool pattern_classes(sb_matrix* m, PatternPlan& P)
   P.meta.resize(m->nChunks);
   sb_d2h(P.meta.data(), m->pmeta, P.meta.size() * sizeof(PackMeta));
   for (const PackMeta& pm : P.meta)
-    if ((pm.info & 0x7FFFFFFFu) >= PAT_NOPAD) return false; // chunk width collides with the header's flag bits
+    if ((pm.info & 0x7FFFFFFFu) > PAT_LEN_MASK) return false; // chunk width collides with the header's flag bits
   P.groups = (uint64_t)P.meta.back().grp + ((P.meta.back().info & 0x7FFFFFFFu) + 3u) / 4u;
   std::vector<double> dict(256);
   sb_d2h(dict.data(), m->pdict, 256 * sizeof(double));
@@ -364,6 +379,31 @@ static bool pattern_classes(sb_matrix* m, PatternPlan& P)
       else e.off8 = (uint32_t)(8 * ((int32_t)((key >> 8) & 0xFFFFu) - 32768)), e.m = 1u; // 8 * (slot - rowBase), mod 2^32
     }
   return true;
+}
+
+// class tables to the device; per-lane code words of every chunk (its L form); the dominant sequence of every
+// chunk + its odd lanes
+static void pattern_codes(sb_matrix* m, PatternPlan& P)
+{
+  std::vector<uint32_t> classKeys(P.classes.size() * 256, PAT_EMPTY);
+  for (size_t c = 0; c < P.classes.size(); c++) std::copy(P.classes[c].begin(), P.classes[c].end(), classKeys.begin() + c * 256);
+  uint32_t* dClassKeys = (uint32_t*)upload(classKeys.data(), classKeys.size() * sizeof(uint32_t));
+  P.dTileClass         = (uint32_t*)upload(P.tileClass.data(), P.tileClass.size() * sizeof(uint32_t));
+  P.dClassDict         = (PatEntry*)upload(P.classDict.data(), P.classDict.size() * sizeof(PatEntry));
+  uint32_t* dDom = nullptr;
+  HIP_CHECK(hipMalloc(&P.dLanes, (size_t)P.groups * 256 + 1024));
+  HIP_CHECK(hipMalloc(&dDom, (size_t)P.groups * sizeof(uint32_t) + 16));
+  HIP_CHECK(hipMalloc(&P.dExc, (size_t)m->nChunks * 2 * sizeof(uint32_t)));
+  hipLaunchKernelGGL(pat_encode_k, dim3(P.nTiles), dim3(64 * P.cpt), 0, g.stream, m->pmeta, P.slots, m->pcodes,
+      m->nChunks, P.dRowBase, P.dTileClass, dClassKeys, P.dLanes);
+  hipLaunchKernelGGL(pat_dominant_k, dim3((m->nChunks + 3) / 4), dim3(256), 0, g.stream, m->pmeta, P.dLanes, m->nChunks, dDom,
+      P.dExc);
+  HIP_CHECK(hipGetLastError());
+  P.dom.resize(P.groups ? P.groups : 1);
+  P.exc.resize((size_t)m->nChunks * 2);
+  sb_d2h(P.dom.data(), dDom, (size_t)P.groups * sizeof(uint32_t));
+  sb_d2h(P.exc.data(), P.dExc, P.exc.size() * sizeof(uint32_t));
+  sb_free(dDom), sb_free(dClassKeys);
 }
 
 // chunk by chunk: U (row pattern + expanded exception lanes) or L (code words of all 64 lanes); row
@@ -434,7 +474,7 @@ static void pattern_rows(sb_matrix* m, PatternPlan& P, const std::vector<uint32_
 // not have to wait for the halo exchange (loop_body).  4-chunk tiles: one TileHdr (48 words); 8-chunk tiles: two
 // TileHdr halves interleaved word by word into 128 words (X: the tile-level fields + chunks 0-3, Y: the per-chunk
 // fields of chunks 4-7), which the kernel fetches as one 8-byte vector load.  Returns the number of segments.
-static size_t pattern_headers(sb_matrix* m, const PatternPlan& P)
+static size_t pattern_headers(sb_matrix* m, const PatternPlan& P, uint32_t** out)
 {
   const uint32_t nTiles = P.nTiles, cpt = P.cpt, LONG = cpt == 8 ? 4u : 3u;
   const std::vector<uint32_t>& segPtr = P.segPtr;
@@ -473,6 +513,10 @@ static size_t pattern_headers(sb_matrix* m, const PatternPlan& P)
       h.win = sg.lds + sg.len;
     }
     h.flags = simple ? PAT_SIMPLE_WINDOW : 0u;
+    if (P.mapped) { // staged through the slot map: the segment words hold the base column of every 256 slots
+      h.flags = PAT_MAPPED_WINDOW;
+      memcpy(&h.seg[0][0], P.blockBase.data() + (size_t)t * 18, 18 * sizeof(uint32_t));
+    }
   }
   m->patInterior = nTiles;
   if (m->nc > m->nr) {
@@ -498,8 +542,8 @@ static size_t pattern_headers(sb_matrix* m, const PatternPlan& P)
       for (uint32_t i = 0; i < 48; i++) o[2 * i] = wx[i], o[2 * i + 1] = wy[i];
     else memcpy(o, wx, 48 * sizeof(uint32_t));
   }
-  m->tileHdrs = (uint32_t*)upload(words.data(), words.size() * sizeof(uint32_t));
-  if (getenv("SB_PACK_REPORT")) {
+  *out = (uint32_t*)upload(words.data(), words.size() * sizeof(uint32_t));
+  if (getenv("SB_PACK_REPORT") && out == &m->tileHdrs) {
     size_t nSimple = 0;
     for (const Pair& h : hdrs) nSimple += h.x.flags & PAT_SIMPLE_WINDOW;
     fprintf(stderr, "sbhip pack: %u tiles of %u chunks (%u interior, %zu simple windows, max %u entries), %zu classes, %u/%u U chunks, "
@@ -508,6 +552,272 @@ static size_t pattern_headers(sb_matrix* m, const PatternPlan& P)
         P.rowPats.size(), (unsigned long long)P.excEntries, P.excLds, (unsigned long long)P.words);
   }
   return nSegs;
+}
+
+// Level 6 (pack.hip.h): every chunk as a row program of its tile + per-row base slots, where the rows allow it.
+// `dom`: dominant code words per group; `lanes` (device): per-lane code words of every chunk.  Built next to the
+// level-5 form (same tiles, windows, classes); kept when nearly all chunks qualify.
+// P: a finished analysis (windows, classes, per-lane codes, dominant sequences).  true: kept (m->m* set).
+static bool build_masked(sb_matrix* m, const PatternPlan& P)
+{
+  const char* env = getenv("SB_PACK");
+  if ((env ? atoi(env) : 6) < 6 || m->nChunks == 0) return false;
+  const std::vector<uint32_t>& dom = P.dom;
+  std::vector<uint32_t> codes((size_t)P.groups * 64);
+  std::vector<uint16_t> rowBase((size_t)m->nChunks * 64);
+  sb_d2h(codes.data(), P.dLanes, codes.size() * sizeof(uint32_t));
+  sb_d2h(rowBase.data(), P.dRowBase, rowBase.size() * sizeof(uint16_t));
+  struct Ent { uint64_t v; int32_t off; }; // value bits, byte offset relative to 8 * base slot
+  PatternPlan Q;
+  Q.nTiles = P.nTiles, Q.cpt = P.cpt, Q.segPtr = P.segPtr, Q.segs = P.segs, Q.tileClass = P.tileClass;
+  Q.mapped = P.mapped, Q.mapStride = P.mapStride, Q.blockBase = P.blockBase;
+  Q.chunkOff.assign(m->nChunks, 0), Q.chunkFlags.assign(m->nChunks, 0), Q.chunkPat.assign(m->nChunks, 0);
+  Q.tileExcStart.assign(P.nTiles, 0), Q.tileExcCount.assign(P.nTiles, 0);
+  Q.exc.assign((size_t)m->nChunks * 2, 0);
+  std::vector<int16_t> mBase((size_t)m->nChunks * 64, 0);
+  for (size_t i = 0; i < mBase.size(); i++) mBase[i] = (int16_t)rowBase[i]; // (L chunks keep the slot of the row's first element)
+  std::vector<ProgBlock> progs;
+  std::unordered_map<std::string, uint32_t> progIndex;
+  const size_t maxProgBlocks = 1u << 16; // 12 MiB of programs at most
+  uint32_t nMasked = 0, nNonEmpty = 0;
+  std::vector<std::vector<Ent>> cand; // the tile's candidate programs: dominant rows of its chunks, longest first
+  std::vector<Ent> rowE;
+  std::vector<ProgBlock> prog;
+  std::vector<uint64_t> emask;
+  std::vector<int32_t> base(64);
+  for (uint32_t t = 0; t < P.nTiles; t++) {
+    const uint32_t c0 = t * P.cpt, c1 = std::min(c0 + P.cpt, m->nChunks);
+    const PatEntry* cd = P.classDict.data() + (size_t)P.tileClass[t] * 256;
+    // entries of a code sequence (real ones; false: a padding entry in front of a real one -- not handled here)
+    auto expand = [&](auto&& code_at, uint32_t len, std::vector<Ent>& out) {
+      out.clear();
+      bool padSeen = false;
+      for (uint32_t j = 0; j < len; j++) {
+        const PatEntry& e = cd[code_at(j)];
+        if (e.m == 0u) { padSeen = true; continue; }
+        if (padSeen) return false;
+        uint64_t vb;
+        memcpy(&vb, &e.v, 8);
+        out.push_back(Ent{ vb, (int32_t)e.off8 });
+      }
+      return true;
+    };
+    cand.clear();
+    std::vector<int> candOf(c1 - c0, -1);
+    for (uint32_t c = c0; c < c1; c++) {
+      const uint32_t len = P.meta[c].info & 0x7FFFFFFFu;
+      if (!len) continue;
+      std::vector<Ent> d;
+      const uint32_t grp = P.meta[c].grp;
+      if (!expand([&](uint32_t j) { return (dom[grp + j / 4] >> (8u * (j & 3u))) & 255u; }, len, d) || d.empty()) continue;
+      int found = -1;
+      for (size_t k = 0; k < cand.size() && found < 0; k++)
+        if (cand[k].size() == d.size() && !memcmp(cand[k].data(), d.data(), d.size() * sizeof(Ent))) found = (int)k;
+      if (found < 0) cand.push_back(std::move(d)), found = (int)cand.size() - 1;
+      candOf[c - c0] = found;
+    }
+    std::vector<int> order(cand.size());
+    for (size_t k = 0; k < order.size(); k++) order[k] = (int)k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cand[a].size() > cand[b].size(); });
+    for (uint32_t c = c0; c < c1; c++) {
+      const uint32_t len = P.meta[c].info & 0x7FFFFFFFu, ng = (len + 3u) / 4u, grp = P.meta[c].grp;
+      if (!len) continue;
+      nNonEmpty++;
+      bool done = false;
+      // its own dominant row first, then the tile's other rows from the longest down
+      for (int attempt = -1; attempt < (int)order.size() && !done; attempt++) {
+        const int k = attempt < 0 ? candOf[c - c0] : order[attempt];
+        if (k < 0 || (attempt >= 0 && k == candOf[c - c0])) continue;
+        const std::vector<Ent>& D = cand[k];
+        const uint32_t dl = (uint32_t)D.size();
+        if (dl > 64u * 1024u) continue;
+        emask.assign(dl, 0ull);
+        uint64_t padMask = 0;
+        bool ok          = true;
+        for (uint32_t lane = 0; lane < 64 && ok; lane++) {
+          const uint32_t* cw = codes.data() + (size_t)grp * 64 + lane;
+          if (!expand([&](uint32_t j) { return (cw[(size_t)(j / 4) * 64] >> (8u * (j & 3u))) & 255u; }, len, rowE)) { ok = false; break; }
+          const uint32_t r   = (uint32_t)rowE.size();
+          const int32_t rb8  = 8 * (int32_t)rowBase[(size_t)c * 64 + lane];
+          if (r < len) padMask |= 1ull << lane; // the row has reference padding
+          base[lane] = 0;
+          if (r == 0) continue;
+          if (r > dl) { ok = false; break; }
+          bool fit = false;
+          for (uint32_t j0 = 0; j0 + r <= dl && !fit; j0++) {
+            if (D[j0].v != rowE[0].v) continue;
+            const int32_t b8 = rb8 + rowE[0].off - D[j0].off; // base that puts the row's first entry on program entry j0
+            if (b8 % 8 != 0 || b8 / 8 < -32768 || b8 / 8 > 32767) continue;
+            uint32_t kk = 0; // greedy, left to right: the row's entries as a sub-sequence of the program
+            for (uint32_t j = j0; j < dl && kk < r; j++)
+              if (D[j].v == rowE[kk].v && b8 + D[j].off == rb8 + rowE[kk].off) kk++;
+            if (kk != r) continue;
+            kk = 0;
+            for (uint32_t j = j0; j < dl && kk < r; j++)
+              if (D[j].v == rowE[kk].v && b8 + D[j].off == rb8 + rowE[kk].off) emask[j] |= 1ull << lane, kk++;
+            base[lane] = b8 / 8;
+            fit        = true;
+          }
+          if (!fit) ok = false;
+        }
+        if (!ok) continue;
+        bool full = true;
+        prog.assign((dl + 7) / 8, ProgBlock{});
+        for (uint32_t j = 0; j < dl; j++) {
+          ProgBlock& pb = prog[j / 8];
+          memcpy(&pb.v[j & 7u], &D[j].v, 8), pb.mask[j & 7u] = emask[j], pb.off8[j & 7u] = (uint32_t)D[j].off;
+          full = full && emask[j] == ~0ull;
+        }
+        std::string key((const char*)prog.data(), prog.size() * sizeof(ProgBlock));
+        auto it = progIndex.find(key);
+        uint32_t at;
+        if (it != progIndex.end()) at = it->second;
+        else if (progs.size() + prog.size() <= maxProgBlocks) {
+          at = (uint32_t)progs.size();
+          progIndex.emplace(std::move(key), at);
+          progs.insert(progs.end(), prog.begin(), prog.end());
+        } else break; // table full: L chunk
+        Q.chunkPat[c]   = at;
+        Q.chunkFlags[c] = dl | PAT_UNIFORM | (full ? PAT_NOPAD : 0u) | (padMask ? PAT_HASPAD : 0u);
+        Q.exc[2 * (size_t)c] = (uint32_t)padMask, Q.exc[2 * (size_t)c + 1] = (uint32_t)(padMask >> 32);
+        for (uint32_t lane = 0; lane < 64; lane++) mBase[(size_t)c * 64 + lane] = (int16_t)base[lane];
+        nMasked++;
+        done = true;
+      }
+      if (!done) {
+        Q.chunkOff[c]   = (uint32_t)Q.words;
+        Q.chunkFlags[c] = len;
+        Q.words += (uint64_t)ng * 64u;
+        Q.anyL = true;
+      }
+    }
+  }
+  const bool keep = nNonEmpty > 0 && (double)nMasked >= 0.98 * (double)nNonEmpty && Q.words <= 0xFFFFFFFFull;
+  if (getenv("SB_PACK_REPORT"))
+    fprintf(stderr, "sbhip pack: masked form%s: %u/%u chunks as row programs (%zu programs, %zu blocks of 8 entries), %llu code words%s\n",
+        P.mapped ? " (windows in original column order)" : "", nMasked, nNonEmpty, progIndex.size(), progs.size(),
+        (unsigned long long)Q.words, keep ? "" : " -- not kept");
+  if (!keep) return false;
+  progs.push_back(ProgBlock{}); // (never empty)
+  uint32_t* dOff   = (uint32_t*)upload(Q.chunkOff.data(), Q.chunkOff.size() * sizeof(uint32_t));
+  uint32_t* dFlags = (uint32_t*)upload(Q.chunkFlags.data(), Q.chunkFlags.size() * sizeof(uint32_t));
+  const size_t streamBytes = (size_t)Q.words * sizeof(uint32_t) + 1024;
+  HIP_CHECK(hipMalloc(&m->mStream, streamBytes));
+  HIP_CHECK(hipMemsetAsync(m->mStream, 0, streamBytes, g.stream));
+  hipLaunchKernelGGL(pat_compact_k, dim3((m->nChunks + 3) / 4), dim3(256), 0, g.stream, m->pmeta, P.dLanes, m->nChunks, dOff,
+      dFlags, P.dExc, P.dRowBase, P.dTileClass, P.dClassDict, m->mStream, (PatEntry*)nullptr, P.cpt);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  sb_free(dOff), sb_free(dFlags);
+  HIP_CHECK(hipMalloc(&m->mRowBase, mBase.size() * sizeof(int16_t) + 16));
+  HIP_CHECK(hipMemcpy(m->mRowBase, mBase.data(), mBase.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+  m->mProgs        = (ProgBlock*)upload(progs.data(), progs.size() * sizeof(ProgBlock));
+  m->nProgs        = (uint32_t)progIndex.size();
+  m->nMaskedChunks = nMasked;
+  m->mDict         = Q.anyL ? 256u : 0u;
+  m->mClassDict    = P.dClassDict; // (shared with the level-5 form unless the windows are the mapped ones)
+  const size_t nSegs = pattern_headers(m, Q, &m->mHdrs);
+  m->mBytes = (double)Q.words * 4.0 + 2.0 * 64.0 * m->nChunks + (P.mapped ? 2.0 * P.mapStride * P.nTiles : 16.0 * nSegs) +
+              (double)(P.cpt == 8 ? 384 : 192) * P.nTiles + (Q.anyL ? 4096.0 * P.classes.size() : 0.0) + 192.0 * progs.size();
+  return true;
+}
+
+// Level 6 for a row-permuted matrix (sigma > 1).  In the device numbering the sort has moved the short rows of
+// every sigma window to its end, so the neighbours of the rows next to them sit at odd distances: no shared
+// program.  The window is therefore laid out in ORIGINAL column order -- there a row and its neighbours keep
+// their distances whatever the sort did -- and staged through a 16-bit map, slot -> device column (relative to
+// a base per 256 slots), instead of segment by segment.
+static void build_masked_mapped(sb_matrix* m, uint32_t cpt, const uint32_t* chunkPtr, const uint32_t* chunkLens,
+    const uint32_t* colInd, const double* val)
+{
+  const char* env = getenv("SB_PACK");
+  if ((env ? atoi(env) : 6) < 6 || m->nChunks == 0) return;
+  TileWindows W = compute_tile_windows(m, cpt, chunkPtr, chunkLens, colInd, val, nullptr, true);
+  if (!W.ok) return;
+  PatternPlan P;
+  P.cpt = cpt, P.nTiles = (m->nChunks + cpt - 1) / cpt, P.mapped = true;
+  // slot -> device column; a block of 256 slots must span < 65536 device columns: where it would not, the
+  // segment that starts inside the block is moved up to the next block boundary
+  std::vector<uint32_t> o2n(m->nr);
+  sb_d2h(o2n.data(), m->oldToNew, o2n.size() * sizeof(uint32_t));
+  auto dev_col = [&](uint32_t orig) { return orig < m->nr ? o2n[orig] : orig; };
+  uint32_t maxWin = 1;
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1) {
+      P.mapStride = ((maxWin + 255u) / 256u) * 256u;
+      if (P.mapStride > (cpt == 8 ? 15u : 12u) * 256u) return; // what a workgroup stages in one pass (spmv_scs64_pat: WB); block bases: <= 18 header words
+      P.slotMap.assign((size_t)P.nTiles * P.mapStride, 0), P.blockBase.assign((size_t)P.nTiles * 18, 0);
+    }
+    for (uint32_t t = 0; t < P.nTiles; t++) {
+      const uint32_t s0 = W.segPtr[t], s1 = W.segPtr[t + 1];
+      if (pass == 0) { // slots: keep a block's device columns within 16 bits
+        uint32_t win = 1, blk = 0xFFFFFFFFu, lo = 0, hi = 0;
+        for (uint32_t s2 = s0; s2 < s1; s2++) {
+          TileSeg& sg = W.segs[s2];
+          for (int tries = 0; tries < 2; tries++) {
+            uint32_t w = win, b = blk, l = lo, h = hi;
+            bool fits = true;
+            for (uint32_t i = 0; i < sg.len && fits; i++, w++) {
+              const uint32_t d = dev_col(sg.col + i);
+              if (w / 256u != b) b = w / 256u, l = h = d;
+              l = std::min(l, d), h = std::max(h, d);
+              fits = h - l < 65536u;
+            }
+            if (fits) { sg.lds = win, win = w, blk = b, lo = l, hi = h; break; }
+            if (tries == 1) return; // a single segment whose device columns are too far apart
+            win = (win + 255u) / 256u * 256u; // start the segment on a block boundary
+          }
+        }
+        if (win > 6144u) return;
+        maxWin = std::max(maxWin, win);
+      } else {
+        uint16_t* mp  = P.slotMap.data() + (size_t)t * P.mapStride;
+        uint32_t* bb  = P.blockBase.data() + (size_t)t * 18;
+        std::vector<uint32_t> dcol(P.mapStride, 0xFFFFFFFFu);
+        for (uint32_t s2 = s0; s2 < s1; s2++)
+          for (uint32_t i = 0; i < W.segs[s2].len; i++) dcol[W.segs[s2].lds + i] = dev_col(W.segs[s2].col + i);
+        for (uint32_t b = 0; b < P.mapStride / 256u; b++) {
+          uint32_t lo = 0xFFFFFFFFu;
+          for (uint32_t i = 0; i < 256; i++) lo = std::min(lo, dcol[b * 256u + i]);
+          if (lo == 0xFFFFFFFFu) lo = m->padCol;
+          bb[b] = lo;
+          for (uint32_t i = 0; i < 256; i++) mp[b * 256u + i] = dcol[b * 256u + i] == 0xFFFFFFFFu ? 0 : (uint16_t)(dcol[b * 256u + i] - lo);
+        }
+      }
+    }
+  }
+  P.segPtr = std::move(W.segPtr), P.segs = std::move(W.segs);
+  // window slots of every element: pack_slots_k on the columns in original numbering (device copy, un-remapped)
+  uint32_t *origCol = nullptr, *slots = nullptr;
+  HIP_CHECK(hipMalloc(&origCol, ((size_t)m->nElems + SCS_SLACK) * sizeof(uint32_t)));
+  HIP_CHECK(hipMemcpy(origCol, m->colInd, ((size_t)m->nElems + SCS_SLACK) * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+  hipLaunchKernelGGL(remap_cols_k, dim3(stream_grid(m->nElems, 256)), dim3(256), 0, g.stream, m->nElems, m->nr, m->newToOld, origCol);
+  uint32_t* dSegPtr = (uint32_t*)upload(P.segPtr.data(), P.segPtr.size() * sizeof(uint32_t));
+  TileSeg* dSegs    = (TileSeg*)upload(P.segs.data(), P.segs.size() * sizeof(TileSeg));
+  std::vector<PackMeta> meta(m->nChunks);
+  sb_d2h(meta.data(), m->pmeta, meta.size() * sizeof(PackMeta));
+  const uint64_t groups = (uint64_t)meta.back().grp + ((meta.back().info & 0x7FFFFFFFu) + 3u) / 4u;
+  HIP_CHECK(hipMalloc(&slots, (size_t)groups * 512 + 1024));
+  hipLaunchKernelGGL(pack_slots_k, dim3((m->nChunks + 3) / 4), dim3(256), 0, g.stream, m->chunkPtr, m->chunkLens, origCol,
+      m->val, m->pmeta, dSegPtr, dSegs, m->nChunks, 0u /* padding: original column 0 */, slots, cpt);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  sb_free(origCol), sb_free(dSegPtr);
+  P.slots = slots;
+  bool kept = false;
+  if (pattern_classes(m, P)) {
+    pattern_codes(m, P);
+    kept = build_masked(m, P);
+  }
+  sb_free(slots);
+  P.free_temporaries();
+  if (!kept) {
+    P.free_tables(), sb_free(dSegs);
+    return;
+  }
+  m->mOwnsTables = true, m->mSegs = dSegs, m->mWindow = maxWin, m->mMapStride = P.mapStride;
+  m->mSlotMap = (uint16_t*)upload(P.slotMap.data(), P.slotMap.size() * sizeof(uint16_t));
+  sb_free(P.dRowBase), sb_free(P.dTileClass); // (mClassDict stays)
 }
 
 // Chunks per tile of the pattern kernel: 8 (two chunks per wave: one header fetch, window staging and barrier for
@@ -560,42 +870,22 @@ static void build_patterns(sb_matrix* m, const uint32_t* chunkPtr, const uint32_
     sb_free(slots8);
     if (m->patSegs != m->tileSegs) sb_free(m->patSegs);
     m->patSegs = nullptr;
-    sb_free(m->rowBase), sb_free(m->classDict), sb_free(m->tileClass);
-    m->rowBase = nullptr, m->classDict = nullptr, m->tileClass = nullptr;
+    P.free_temporaries(), P.free_tables();
   };
   if (!pattern_classes(m, P)) { // (more pairs than a class holds in some tile: try the smaller tiles before giving up)
     give_up();
     if (P.cpt == 8) build_patterns(m, chunkPtr, chunkLens, colInd, val, oldToNewPerm, 4);
     return;
   }
-  // per-lane code words of every chunk (its L form), then the dominant sequence + odd lanes
-  std::vector<uint32_t> classKeys(P.classes.size() * 256, PAT_EMPTY);
-  for (size_t c = 0; c < P.classes.size(); c++) std::copy(P.classes[c].begin(), P.classes[c].end(), classKeys.begin() + c * 256);
-  uint32_t* dClassKeys = (uint32_t*)upload(classKeys.data(), classKeys.size() * sizeof(uint32_t));
-  m->tileClass         = (uint32_t*)upload(P.tileClass.data(), P.tileClass.size() * sizeof(uint32_t));
-  m->classDict         = (PatEntry*)upload(P.classDict.data(), P.classDict.size() * sizeof(PatEntry));
-  uint32_t *lanes = nullptr, *dDom = nullptr, *dExc = nullptr;
-  HIP_CHECK(hipMalloc(&lanes, (size_t)P.groups * 256 + 1024));
-  HIP_CHECK(hipMalloc(&dDom, (size_t)P.groups * sizeof(uint32_t) + 16));
-  HIP_CHECK(hipMalloc(&dExc, (size_t)m->nChunks * 2 * sizeof(uint32_t)));
-  const uint32_t nBlocks4 = (m->nChunks + 3) / 4;
-  hipLaunchKernelGGL(pat_encode_k, dim3(P.nTiles), dim3(64 * P.cpt), 0, g.stream, m->pmeta, P.slots, m->pcodes,
-      m->nChunks, m->rowBase, m->tileClass, dClassKeys, lanes);
-  hipLaunchKernelGGL(pat_dominant_k, dim3(nBlocks4), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dDom,
-      dExc);
-  HIP_CHECK(hipGetLastError());
-  std::vector<uint32_t> dom(P.groups ? P.groups : 1);
-  P.exc.resize((size_t)m->nChunks * 2);
-  sb_d2h(dom.data(), dDom, (size_t)P.groups * sizeof(uint32_t));
-  sb_d2h(P.exc.data(), dExc, P.exc.size() * sizeof(uint32_t));
-  sb_free(dDom), sb_free(dClassKeys);
-  pattern_rows(m, P, dom, (env ? atoi(env) : 5) >= 5);
+  pattern_codes(m, P);
+  pattern_rows(m, P, P.dom, (env ? atoi(env) : 5) >= 5);
   if (P.words > 0xFFFFFFFFull || P.excEntries > 0xFFFFFFFFull) { // positions are 32-bit
-    sb_free(lanes), sb_free(dExc);
     give_up();
     return;
   }
+  m->rowBase = P.dRowBase, m->tileClass = P.dTileClass, m->classDict = P.dClassDict;
   // final form: L code words / expanded exception rows of the U chunks
+  const uint32_t nBlocks4 = (m->nChunks + 3) / 4;
   uint32_t* dOff   = (uint32_t*)upload(P.chunkOff.data(), P.chunkOff.size() * sizeof(uint32_t));
   uint32_t* dFlags = (uint32_t*)upload(P.chunkFlags.data(), P.chunkFlags.size() * sizeof(uint32_t));
   const size_t streamBytes = (size_t)P.words * sizeof(uint32_t) + 1024;        // slack: clamped reads
@@ -604,24 +894,31 @@ static void build_patterns(sb_matrix* m, const uint32_t* chunkPtr, const uint32_
   HIP_CHECK(hipMalloc(&m->excRows, excBytes));
   HIP_CHECK(hipMemsetAsync(m->jcodes, 0, streamBytes, g.stream));
   HIP_CHECK(hipMemsetAsync(m->excRows, 0, excBytes, g.stream));
-  hipLaunchKernelGGL(pat_compact_k, dim3(nBlocks4), dim3(256), 0, g.stream, m->pmeta, lanes, m->nChunks, dOff,
-      dFlags, dExc, m->rowBase, m->tileClass, m->classDict, m->jcodes, m->excRows, P.cpt);
+  hipLaunchKernelGGL(pat_compact_k, dim3(nBlocks4), dim3(256), 0, g.stream, m->pmeta, P.dLanes, m->nChunks, dOff,
+      dFlags, P.dExc, m->rowBase, m->tileClass, m->classDict, m->jcodes, m->excRows, P.cpt);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(g.stream));
-  sb_free(lanes), sb_free(dExc), sb_free(dOff), sb_free(dFlags), sb_free(slots8);
+  sb_free(dOff), sb_free(dFlags), sb_free(slots8);
+  // level 6 on the same windows; with a row permutation, on windows in original column order
+  if (build_masked(m, P)) m->mSegs = m->patSegs, m->mWindow = m->patWindow;
+  else if (m->permuted) {
+    P.free_temporaries();
+    build_masked_mapped(m, P.cpt, chunkPtr, chunkLens, colInd, val);
+  }
+  P.free_temporaries();
   m->rowPats     = (PatEntry*)upload(P.rowPats.data(), P.rowPats.size() * sizeof(PatEntry));
   m->nRowPats    = (uint32_t)P.nRowPats;
   m->nPatClasses = (uint32_t)P.classes.size();
   m->patDict     = P.anyL ? 256u : 0u;
   m->patExcLds   = P.excLds;
-  const size_t nSegs = pattern_headers(m, P);
+  const size_t nSegs = pattern_headers(m, P, &m->tileHdrs);
   m->patBytes = (double)P.words * 4.0 + 16.0 * (double)P.excEntries + 2.0 * 64.0 * m->nChunks + 16.0 * nSegs +
                 (double)(P.cpt == 8 ? 384 : 192) * P.nTiles + (P.anyL ? 4096.0 * P.classes.size() : 0.0) + 16.0 * P.rowPats.size();
   // Default kernel: the pattern kernel once the matrix is more than one round of resident
   // workgroups (8 per CU, 4 chunks each); below that everything is one dependent-latency chain and the
   // level-3 kernel's is shorter (64^3: 46.7k vs 43.2k CG it/s; 96^3: 22.8k vs 26.3k).
   // sb_matrix_use_packed(m, 3) selects it regardless.
-  m->usePacked = (m->nChunks + 3) / 4 > (uint32_t)g.prop.multiProcessorCount * 8u ? 3 : 2;
+  m->usePacked = (m->nChunks + 3) / 4 > (uint32_t)g.prop.multiProcessorCount * 8u ? (m->mHdrs ? 5 : 3) : 2;
 }
 
 sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, uint32_t nChunks,
@@ -730,7 +1027,7 @@ static void build_crs_mirror(sb_matrix* m, const uint32_t* rowPtr, const uint32_
   sb_free(mm->val), sb_free(mm->colInd), sb_free(mm->pidx), sb_free(mm->pcodes), sb_free(mm->pslots);
   mm->val = nullptr, mm->colInd = nullptr, mm->pidx = nullptr, mm->pcodes = nullptr, mm->pslots = nullptr;
   m->mirror    = mm;
-  m->usePacked = mm->usePacked == 3 ? 3 : 0; // the same size rule as for SCS matrices
+  m->usePacked = mm->usePacked >= 3 ? mm->usePacked : 0; // the same size rule as for SCS matrices
 }
 
 void sb_matrix_free(sb_matrix* m)
@@ -742,6 +1039,8 @@ void sb_matrix_free(sb_matrix* m)
   if (m->patSegs != m->tileSegs) sb_free(m->patSegs);
   sb_free(m->tileSegPtr), sb_free(m->tileSegs), sb_free(m->pslots);
   sb_free(m->rowBase), sb_free(m->tileClass), sb_free(m->jcodes), sb_free(m->classDict), sb_free(m->tileHdrs), sb_free(m->rowPats), sb_free(m->excRows);
+  sb_free(m->mHdrs), sb_free(m->mStream), sb_free(m->mRowBase), sb_free(m->mProgs), sb_free(m->mSlotMap);
+  if (m->mOwnsTables) sb_free(m->mClassDict), sb_free(m->mSegs);
   if (m->mirror) sb_matrix_free(m->mirror);
   delete m;
 }
@@ -750,7 +1049,9 @@ int sb_matrix_pack_level(const sb_matrix* m) { return m->packLevel; }
 void sb_matrix_use_packed(sb_matrix* m, int mode)
 { // 0 reference-layout stream, 1 packed stream + gathers through the cache, 2 packed + LDS window,
   // 3 pattern codes + LDS window; a mode the matrix does not have falls to the next lower one
-  if (m->fmt == 0) m->usePacked = mode >= 3 && m->mirror ? 3 : 0;
+  // (5: the pattern kernel on masked row programs, pack.hip.h level 6)
+  if (m->fmt == 0) m->usePacked = mode >= 5 && m->mirror && m->mirror->mHdrs ? 5 : mode >= 3 && m->mirror ? 3 : 0;
+  else if (mode >= 5 && m->mHdrs) m->usePacked = 5;
   else if (mode >= 3 && m->nPatClasses) m->usePacked = 3;
   else if (mode >= 2 && m->ldsWindow) m->usePacked = 2;
   else if (mode >= 1 && m->packLevel) m->usePacked = 1;
@@ -762,7 +1063,8 @@ static const sb_matrix* pat_of(const sb_matrix* m) { return m->fmt == 0 && m->mi
 uint32_t sb_matrix_lds_window(const sb_matrix* m)
 { // doubles per workgroup of the SELECTED kernel's window (the pattern kernel may use tiles of 8 chunks)
   const sb_matrix* pm = pat_of(m);
-  return pm->usePacked == 3 && pm->patWindow ? pm->patWindow : pm->ldsWindow;
+  if (m->usePacked == 5) return pm->mWindow;
+  return m->usePacked == 3 && pm->patWindow ? pm->patWindow : pm->ldsWindow;
 }
 uint32_t sb_matrix_pattern_classes(const sb_matrix* m) { return pat_of(m)->nPatClasses; }
 uint32_t sb_matrix_row_patterns(const sb_matrix* m, uint32_t* uniformChunks)
@@ -770,8 +1072,15 @@ uint32_t sb_matrix_row_patterns(const sb_matrix* m, uint32_t* uniformChunks)
   if (uniformChunks) *uniformChunks = pat_of(m)->nUniformChunks;
   return pat_of(m)->nRowPats;
 }
+uint32_t sb_matrix_row_programs(const sb_matrix* m, uint32_t* maskedChunks)
+{
+  if (maskedChunks) *maskedChunks = pat_of(m)->nMaskedChunks;
+  return pat_of(m)->nProgs;
+}
 double sb_matrix_stream_bytes(const sb_matrix* m)
 { // bytes the SELECTED SpMV kernel moves per launch (matrix stream + x once + y once)
+  if (m->fmt == 0 && m->usePacked == 5) return m->mirror->mBytes + 8.0 * m->mirror->nrPadded + 8.0 * m->nc;
+  if (m->fmt == 1 && m->usePacked == 5) return m->mBytes + 8.0 * m->nrPadded + 8.0 * m->nc;
   if (m->fmt == 0 && m->usePacked == 3) return m->mirror->patBytes + 8.0 * m->mirror->nrPadded + 8.0 * m->nc;
   if (m->fmt == 1 && m->usePacked == 3) return m->patBytes + 8.0 * m->nrPadded + 8.0 * m->nc;
   if (m->fmt == 1 && m->usePacked == 2) return m->slotBytes + 8.0 * m->nrPadded + 8.0 * m->nc;

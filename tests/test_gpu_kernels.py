@@ -38,12 +38,13 @@ def gpu_spmv(L, m, x, nr):
     L.sb_spmv(m, dx.ptr, dy.ptr)
     y = dy.get()
     # every kernel the matrix has (0 reference stream / native CRS, 1 packed + cache gathers, 2 packed + LDS window,
-    # 3 pattern codes + LDS window, 4 row patterns; CRS: through its private mirror) must give the same bits.
+    # 3 pattern codes / row patterns + LDS window, 5 masked row programs; CRS: through its private mirror) must give
+    # the same bits.
     # Where the result is NaN only the NaN-ness is compared (which NaN payload an add of two NaNs returns depends
     # on operand order, not on the algorithm)
     best = L.sb_matrix_packed_mode(m)
     tried = set()
-    for mode in (0, 1, 2, 3, 4):
+    for mode in (0, 1, 2, 3, 5):
         L.sb_matrix_use_packed(m, mode)
         got = L.sb_matrix_packed_mode(m)
         if got in tried:
@@ -212,8 +213,17 @@ def test_pattern_dictionary_mode(gpu, monkeypatch):
                     # (70 x 3 x 5 mixes U and L chunks inside its tiles)
                     assert pats >= 1 and uni.value >= (0.7 * s.nChunks if dims[0] >= 128 else 1), \
                         (dims, sg, pats, uni.value, s.nChunks)
+                if pack is None and dims[0] >= 128:
+                    # ... and the odd lanes (rows next to the grid boundary, rows the sigma sort moved) are
+                    # sub-sequences of their tile's longer rows: every chunk becomes a masked row program
+                    mch = C.c_uint32(0)
+                    progs = L.sb_matrix_row_programs(m, C.byref(mch))
+                    assert progs >= 1 and mch.value == s.nChunks, (dims, sg, progs, mch.value, s.nChunks)
+                    L.sb_matrix_use_packed(m, 5)
+                    assert L.sb_matrix_packed_mode(m) == 5
+                    L.sb_matrix_use_packed(m, 2)
             if pack:
-                assert pats == 0 and uni.value == 0
+                assert pats == 0 and uni.value == 0 and L.sb_matrix_row_programs(m, None) == 0
             x = rng.standard_normal(g.nc)
             assert np.array_equal(gpu_spmv(L, m, x, g.nr), g.spmv(x))
             # NaN / Inf in x reach exactly the rows the reference lets them reach (padding -> x[padCol])
