@@ -790,7 +790,7 @@ static void build_masked_mapped(sb_matrix* m, uint32_t cpt, const uint32_t* chun
   // window slots of every element: pack_slots_k on the columns in original numbering (device copy, un-remapped)
   uint32_t *origCol = nullptr, *slots = nullptr;
   HIP_CHECK(hipMalloc(&origCol, ((size_t)m->nElems + SCS_SLACK) * sizeof(uint32_t)));
-  HIP_CHECK(hipMemcpy(origCol, m->colInd, ((size_t)m->nElems + SCS_SLACK) * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+  sb_d2d(origCol, m->colInd, ((size_t)m->nElems + SCS_SLACK) * sizeof(uint32_t)); // (on g.stream, like the kernels below)
   hipLaunchKernelGGL(remap_cols_k, dim3(stream_grid(m->nElems, 256)), dim3(256), 0, g.stream, m->nElems, m->nr, m->newToOld, origCol);
   uint32_t* dSegPtr = (uint32_t*)upload(P.segPtr.data(), P.segPtr.size() * sizeof(uint32_t));
   TileSeg* dSegs    = (TileSeg*)upload(P.segs.data(), P.segs.size() * sizeof(TileSeg));
