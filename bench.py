@@ -280,7 +280,7 @@ def spawn_ranks(n_gpus, argv):
 # ------------------------------------------------------------------------------------------------
 def kernel_name(fmt, mode):
     native = "spmv_crs_stream" if fmt == "crs" else "spmv_scs64"
-    return [native, "spmv_scs64_packed", "spmv_scs64_lds", "spmv_scs64_pat"][mode]
+    return {0: native, 1: "spmv_scs64_packed", 2: "spmv_scs64_lds", 3: "spmv_scs64_pat", 5: "spmv_scs64_pat_masked"}[mode]
 
 
 def roofline_block(kernel, moved, alg, us, launches, traffic, traffic_src, traffic_note):
@@ -325,6 +325,8 @@ def run_rank(args):
     capi.load()
     ndev = capi.load().sb_device_count()
     L = capi.init(local % ndev if args.transport == "host" and ndev > 0 else local)
+    if world > max(ndev, 1):  # ranks share GPUs (rehearsal): the one-launch vector phase needs a GPU to itself
+        os.environ.setdefault("SB_SHARED_GPU", "1")
     H = hostapi.host()
     version = L.sb_version().decode()
 
@@ -351,11 +353,14 @@ def run_rank(args):
         L.sb_sync()
 
     K, W = args.steps, args.warmup
+    vphase = 0
 
     def measure(prob, modes):
         """timed passes on one resident matrix.  modes: kernel modes to time with per-launch events; the
         first is the one `value` is quoted on (clean pass without events)."""
         cg = hostapi.CG(prob, fused=True, graph=bool(args.graph))
+        nonlocal vphase
+        vphase = cg.vector_phase()
 
         def timed_pass(with_spmv_events):
             """exactly K loop bodies, in segments restarted from x0 = 0 outside the clock"""
@@ -407,9 +412,10 @@ def run_rank(args):
         return res
 
     def vector_bytes(nr):
-        """bytes the fused loop's vector kernels move per iteration: p update (+ the x update owed by the
-        previous body) 40 B/row, r update + r.r partials 24 B/row, partials written and read back"""
-        return 64.0 * nr + 2 * 8.0 * (nr / 64.0)
+        """bytes the fused loop's vector kernels move per iteration.  Separate launches: p update (+ the x update
+        owed by the previous body) 40 B/row, r update + r.r partials 24 B/row.  One-launch vector phase: r, Ap, p, x
+        read and r, p, x written once: 56 B/row.  Plus the partials written and read back."""
+        return (56.0 if vphase else 64.0) * nr + 2 * 8.0 * (nr / 64.0)
 
     out = None
     if not irregular:
@@ -446,7 +452,8 @@ def run_rank(args):
                            "dot_allreduce_reason": (L.sb_comm_p2p_reason().decode() if world > 1 else None),
                            "halo_exchange_reason": (L.sb_halo_p2p_reason(prob.halo).decode() if world > 1 else None),
                            "spmv_x_staging": ("lds_window" if default >= 2 else "l1_l2_gather (LDS staging measured neutral at 12 B/element)"),
-                           "fused_dots": True, "hip_graph": bool(args.graph), "library": version},
+                           "fused_dots": True, "vector_phase_one_launch": bool(vphase), "launches_per_iteration": 2 if vphase else 5,
+                           "hip_graph": bool(args.graph), "library": version},
                 "global_iterations_per_s": it_s,
                 "roofline": roofline_block(kern, d["moved"], d["alg"], d["spmv_us"], d["launches"], *tr),
                 "algorithmic_speedup": d["alg"] / d["moved"],

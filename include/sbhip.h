@@ -204,9 +204,15 @@ void sb_halo_exchange(sb_halo* h, double* x);
 sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host,
                     const double* xexact_host);
 void sb_cg_free(sb_cg* s);
-/* fused = 1: dots fused into the SpMV / update kernels; 0: the reference's op list
- * (waxpby, spMVM, ddot as separate launches).  Same bits either way. */
+/* fused = 0: the reference's op list (waxpby, spMVM, ddot as separate launches); 1 (default): dots fused into the
+ * SpMV / update kernels (5 launches per loop body); 2: additionally the vector phase of a body
+ * (alpha | x, r update + r.r | beta, loop test | p update; src/CGSolver.c:124-128 and :107-116) as ONE launch
+ * whose workgroups wait for each other -- used when this rank has its GPU to itself (SB_SHARED_GPU=1 says it
+ * has not), the all-reduce is the in-kernel one (or there is one rank) and the rows fit the resident grid's
+ * registers; otherwise it behaves as 1.  (Measured slower than 1 at 128^3: sbhip_cg.inc.h.)  Same bits in every mode. */
 void sb_cg_set_fused(sb_cg* s, int fused);
+/* spans per wave of the one-launch vector phase the solver will use, 0 if it will not use it */
+int sb_cg_vector_phase(sb_cg* s);
 void sb_cg_set_graph(sb_cg* s, int use_graph);
 /* Runs solveCG's whole loop without host synchronisation; returns k exactly as
  * the reference does (src/CGSolver.c:140).  Blocking. */

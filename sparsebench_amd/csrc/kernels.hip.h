@@ -777,6 +777,205 @@ __global__ __launch_bounds__(1024) void cg_scalar_p2p_k(uint32_t m, const double
 }
 
 // =============================================================================
+// The vector phase of a CG body as ONE launch (cg_vector_phase_k): alpha | x, r update + r.r | beta, loop
+// test | p update -- src/CGSolver.c:124-128 of body k and :107-116 of body k+1.  As separate launches these
+// are four dependent kernels (two of them single-workgroup scalar steps); a kernel boundary on this part
+// costs ~4 us (eight L2s to write back and invalidate), the four kernels move 134 MB, and r travels to memory
+// and back between them.  Here every thread keeps its elements of r, p, x, Ap in registers across the
+// two scalar steps; the steps themselves are taken by workgroup 0 while the others wait on a flag:
+//   A  all: load r, Ap, p, x.   WG 0: levels 1-2 of p.Ap (partials written by the SpMV), [all-reduce],
+//      alpha; publishes alpha.
+//   B  all: r -= alpha Ap, x += alpha p (stored), level-0 partials of r.r (stored), then count in.
+//   C  WG 0: once every workgroup has counted in: levels 1-2 of r.r, [all-reduce], beta and the loop test;
+//      publishes beta and the stop flag.
+//   D  all: p = r + beta p (unless the loop has ended).
+// The arithmetic per element and the dot order are those of the separate kernels: same bits.
+// What crosses workgroups inside the launch (partials, alpha, beta, the flags, the counter) travels by
+// agent-scope relaxed atomics -- on this part they bypass the XCD-private L2s -- ordered by "all my stores are
+// acknowledged" (s_waitcnt vmcnt(0)) in front of the flag / the count; no L2 write-back fence anywhere.
+// The grid is sized so that every workgroup is resident (the waits would otherwise never end); all waits
+// are bounded by a wall-clock timeout that raises VPhase::error (the host reports it at the end of the solve).
+// =============================================================================
+struct VPhase { // device control block, zeroed once
+  unsigned long long arrived;  // workgroups that have finished phase B, over all launches
+  unsigned long long launches; // finished launches (the next launch's sequence number - 1)
+  unsigned long long flagA, alphaBits;
+  unsigned long long flagB, betaBits, stopB;
+  int error;
+};
+
+__device__ __forceinline__ unsigned long long vp_load(const unsigned long long* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void vp_store(unsigned long long* p, unsigned long long v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void vp_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// thread 0 of the workgroup: wait until *flag >= want (bounded); false on timeout
+__device__ __forceinline__ bool vp_wait(const unsigned long long* flag, unsigned long long want, long long timeoutTicks)
+{
+  const long long t0 = wall_clock64();
+  while (vp_load(flag) < want) {
+    if (wall_clock64() - t0 > timeoutTicks) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return true;
+}
+
+// reduce_final_1024 on partials written during THIS launch by other workgroups (agent-scope loads)
+__device__ __forceinline__ double reduce_final_1024_coherent(uint32_t m, const double* q, double* lds16)
+{
+  auto l1 = [&](uint32_t i) {
+    const unsigned long long* w = reinterpret_cast<const unsigned long long*>(q) + 4u * (size_t)i;
+    const double a = __longlong_as_double((long long)vp_load(w)), b = __longlong_as_double((long long)vp_load(w + 1));
+    const double c = __longlong_as_double((long long)vp_load(w + 2)), d = __longlong_as_double((long long)vp_load(w + 3));
+    return ((a + b) + c) + d;
+  };
+  double s   = 0.0;
+  uint32_t i = threadIdx.x;
+  for (; i + 3u * 1024u < m; i += 4u * 1024u) { // 16 loads in flight (the same sequence of additions as reduce_final_1024)
+    double a[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) a[u] = l1(i + (uint32_t)u * 1024u);
+#pragma unroll
+    for (int u = 0; u < 4; u++) s = s + a[u];
+  }
+  for (; i < m; i += 1024u) s = s + l1(i);
+  s = butterfly64(s);
+  if ((threadIdx.x & 63u) == 0) lds16[threadIdx.x >> 6] = s;
+  __syncthreads();
+  double total = lds16[0];
+#pragma unroll
+  for (int w = 1; w < 16; w++) total = total + lds16[w];
+  return total;
+}
+
+// SP: spans (128 consecutive elements, two per lane) a wave keeps in registers; the host picks the
+// instantiation and a grid of resident workgroups with nSpans <= 16 * gridDim.x * SP.
+template <int SP, bool P2P>
+__global__ __launch_bounds__(1024) void cg_vector_phase_k(uint32_t n, double* r, double* p, const double* __restrict__ Ap,
+    double* x, CgScalars* S, const double* __restrict__ pApPartials, double* rrPartials, uint32_t m,
+    double* __restrict__ rr_hist, double* __restrict__ pAp_hist, VPhase* V, long long timeoutTicks, const P2PView* pv,
+    unsigned long long p2pSeq)
+{
+  __shared__ double lds16[16];
+  __shared__ double shVal;
+  __shared__ int shFlag; // 0 go on, 1 loop ended, 2 error
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = blockIdx.x * 16u + (threadIdx.x >> 6), nWaves = gridDim.x * 16u;
+  const uint32_t nSpans = ((n + 255u) >> 8) * 2u;
+  double2 rv[SP], av[SP], pw[SP], xv[SP];
+#pragma unroll
+  for (int k = 0; k < SP; k++) {
+    const uint32_t e = (wave + (uint32_t)k * nWaves) * 128u + lane * 2u;
+    rv[k] = av[k] = pw[k] = xv[k] = double2{ 0.0, 0.0 };
+    if (e + 1 < n) {
+      rv[k] = *reinterpret_cast<const double2*>(r + e), av[k] = *reinterpret_cast<const double2*>(Ap + e);
+      pw[k] = *reinterpret_cast<const double2*>(p + e), xv[k] = *reinterpret_cast<const double2*>(x + e);
+    } else if (e < n) {
+      rv[k].x = r[e], av[k].x = Ap[e], pw[k].x = p[e], xv[k].x = x[e];
+    }
+  }
+  const int stopped            = S->stop;
+  const unsigned long long seq = V->launches + 1ull;
+  if (stopped) return; // every workgroup sees the same flag: it only changes in phase C, after all have read it
+  // ---- A: alpha -------------------------------------------------------------------------------------
+  if (blockIdx.x == 0) {
+    double total = reduce_final_1024(m, pApPartials, lds16);
+    __syncthreads();
+    if (P2P) total = p2p_allreduce_sum(pv, total, p2pSeq, lds16, &S->p2p_error);
+    if (threadIdx.x == 0) {
+      cg_apply<2>(S, total, rr_hist, pAp_hist, 0);
+      vp_store(&V->alphaBits, (unsigned long long)__double_as_longlong(S->alpha));
+      vp_stores_done();
+      vp_store(&V->flagA, seq);
+    }
+  }
+  if (threadIdx.x == 0) {
+    const bool ok = vp_wait(&V->flagA, seq, timeoutTicks);
+    shVal  = __longlong_as_double((long long)vp_load(&V->alphaBits));
+    shFlag = ok ? 0 : 2;
+  }
+  __syncthreads();
+  if (shFlag == 2) { // (uniform per workgroup) a wait timed out: not every workgroup is running
+    if (threadIdx.x == 0) atomicExch(&V->error, 1), S->stop = 1; // (stop: the bodies already enqueued return at once)
+    return;
+  }
+  const double alpha = shVal, nalpha = -alpha;
+  // ---- B: x, r, level 0 of r.r ------------------------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < SP; k++) {
+    const uint32_t sp = wave + (uint32_t)k * nWaves, e = sp * 128u + lane * 2u;
+    double t = 0.0;
+    if (e + 1 < n) {
+      xv[k].x = xv[k].x + alpha * pw[k].x, xv[k].y = xv[k].y + alpha * pw[k].y;
+      rv[k].x = rv[k].x + nalpha * av[k].x, rv[k].y = rv[k].y + nalpha * av[k].y;
+      *reinterpret_cast<double2*>(x + e) = xv[k];
+      *reinterpret_cast<double2*>(r + e) = rv[k];
+      t = rv[k].x * rv[k].x + rv[k].y * rv[k].y;
+    } else if (e < n) {
+      xv[k].x = xv[k].x + alpha * pw[k].x;
+      rv[k].x = rv[k].x + nalpha * av[k].x;
+      x[e] = xv[k].x, r[e] = rv[k].x;
+      t    = rv[k].x * rv[k].x + 0.0;
+    }
+    t = butterfly32(t);
+    if (sp < nSpans && (lane & 31u) == 0)
+      vp_store(reinterpret_cast<unsigned long long*>(rrPartials) + sp * 2u + (lane >> 5), (unsigned long long)__double_as_longlong(t));
+  }
+  vp_stores_done();
+  __syncthreads(); // (also: nobody overwrites shVal / shFlag before everybody has read them)
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(&V->arrived, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- C: beta, loop test ------------------------------------------------------------------------------
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) shFlag = vp_wait(&V->arrived, (unsigned long long)gridDim.x * seq, timeoutTicks) ? 0 : 2;
+    __syncthreads();
+    if (shFlag != 2) {
+      double total = reduce_final_1024_coherent(m, rrPartials, lds16);
+      __syncthreads();
+      if (P2P) total = p2p_allreduce_sum(pv, total, p2pSeq + 1ull, lds16, &S->p2p_error);
+      if (threadIdx.x == 0) {
+        cg_apply<1>(S, total, rr_hist, pAp_hist, 0);
+        if (P2P && __hip_atomic_load(&S->p2p_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) S->stop = 1;
+        vp_store(&V->betaBits, (unsigned long long)__double_as_longlong(S->beta));
+        vp_store(&V->stopB, (unsigned long long)S->stop);
+        vp_stores_done();
+        vp_store(&V->flagB, seq);
+        V->launches = seq;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const bool ok = vp_wait(&V->flagB, seq, timeoutTicks);
+    shVal  = __longlong_as_double((long long)vp_load(&V->betaBits));
+    shFlag = !ok ? 2 : vp_load(&V->stopB) ? 1 : 0;
+  }
+  __syncthreads();
+  if (shFlag == 2) {
+    if (threadIdx.x == 0) atomicExch(&V->error, 1), S->stop = 1; // (stop: the bodies already enqueued return at once)
+    return;
+  }
+  if (shFlag == 1) return; // the loop has ended: p stays (the separate p update returns on the stop flag too)
+  // ---- D: p = r + beta p ---------------------------------------------------------------------------------
+  const double beta = shVal;
+#pragma unroll
+  for (int k = 0; k < SP; k++) {
+    const uint32_t e = (wave + (uint32_t)k * nWaves) * 128u + lane * 2u;
+    if (e + 1 < n) {
+      double2 o;
+      o.x = rv[k].x + beta * pw[k].x, o.y = rv[k].y + beta * pw[k].y;
+      *reinterpret_cast<double2*>(p + e) = o;
+    } else if (e < n) {
+      p[e] = rv[k].x + beta * pw[k].x;
+    }
+  }
+}
+
+// =============================================================================
 // permutation / halo helpers
 // =============================================================================
 __global__ __launch_bounds__(256) void gather_k(uint32_t n, const uint32_t* __restrict__ idx,

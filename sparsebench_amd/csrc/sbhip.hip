@@ -272,6 +272,11 @@ struct sb_cg {
   int k_next;        // next loop body to enqueue
   bool started;
   CgScalars hostS;   // staging copy for the H2D of the control block
+  // fused >= 2: the vector phase of a body as one launch (kernels.hip.h: cg_vector_phase_k)
+  VPhase* vphase    = nullptr;
+  double* partials2 = nullptr; // level-0 partials of r.r (the p.Ap ones stay in `partials` while it reads them)
+  int vSP = -1;                // spans per wave of the chosen instantiation; 0: not eligible; -1: not planned yet
+  uint32_t vGrid = 0;
 };
 
 // ===========================================================================
@@ -280,7 +285,7 @@ struct sb_cg {
 // Every sb_* function below is declared extern "C" by include/sbhip.h, which fixes
 // its linkage; the helpers in between stay C++.
 
-const char* sb_version(void) { return "sparsebench_amd sbhip 0.2 (gfx950)"; }
+const char* sb_version(void) { return "sparsebench_amd sbhip 0.3 (gfx950)"; }
 
 int sb_device_count(void)
 {

@@ -49,6 +49,10 @@ sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host, con
   HIP_CHECK(hipMemsetAsync(s->partials, 0, (4 * (size_t)s->nPartials + 4) * sizeof(double), g.stream));
   s->hist_cap  = 0;
   s->rr_hist = s->pAp_hist = nullptr;
+  s->partials2 = (double*)sb_malloc((4 * (size_t)s->nPartials + 4) * sizeof(double));
+  HIP_CHECK(hipMemsetAsync(s->partials2, 0, (4 * (size_t)s->nPartials + 4) * sizeof(double), g.stream));
+  s->vphase = (VPhase*)sb_malloc(sizeof(VPhase));
+  HIP_CHECK(hipMemsetAsync(s->vphase, 0, sizeof(VPhase), g.stream));
   s->fused      = 1;
   s->use_graph  = 0;
   s->graphReady = false;
@@ -76,7 +80,7 @@ void sb_cg_free(sb_cg* s)
   HIP_CHECK(hipEventDestroy(s->evLoop0));
   HIP_CHECK(hipEventDestroy(s->evLoop1));
   sb_free(s->r), sb_free(s->Ap), sb_free(s->x), sb_free(s->b), sb_free(s->p), sb_free(s->xexact);
-  sb_free(s->S), sb_free(s->partials), sb_free(s->rr_hist), sb_free(s->pAp_hist);
+  sb_free(s->S), sb_free(s->partials), sb_free(s->rr_hist), sb_free(s->pAp_hist), sb_free(s->partials2), sb_free(s->vphase);
   delete s;
 }
 
@@ -87,9 +91,68 @@ static void drop_graph(sb_cg* s)
 }
 
 void sb_cg_set_fused(sb_cg* s, int fused)
-{
-  if (s->fused != fused) drop_graph(s);
+{ // 0: the reference's op list; 1 (default): dots fused into their producers (5 launches per body); 2: + the vector
+  // phase of a body as one launch where that is possible (2 launches per body; measured SLOWER at 128^3, see below)
+  if (s->fused != fused) drop_graph(s), s->vSP = -1;
   s->fused = fused;
+}
+
+// Measured (MI355X, HPCG 128^3, Sell-64-256): 61.1 us per iteration against 51.5 us with the five launches.  The four
+// kernels it replaces overlap their reads and writes freely (134 MB in ~20 us, Infinity-Cache assisted) and pay ~8 us
+// for the two scalar launches; the one launch reads everything, THEN (after alpha) writes r and x, THEN (after beta)
+// writes p: the two grid-wide waits serialise the traffic, and one 1024-thread workgroup per CU is a thin streaming
+// configuration.  Kept selectable (sb_cg_set_fused(s, 2)) and tested, because the protocol -- workgroup 0 takes the
+// scalar step while the others hold their elements in registers -- is what a persistent CG kernel would build on.
+// The one-launch vector phase needs every workgroup of its grid resident at once (they wait for each other):
+// the grid is what the occupancy calculation says fits, and the instantiation the smallest whose registers hold
+// the rank's rows on that grid.  Not used when ranks share a GPU (SB_SHARED_GPU=1: rehearsal with several
+// processes per device -- two such grids would wait for each other's CUs), when the all-reduce is not the
+// in-kernel one, or with SB_VPHASE=0.
+template <int SP, bool P2P> static bool vphase_try(sb_cg* s, uint32_t nSpans)
+{
+  int perCU = 0;
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, cg_vector_phase_k<SP, P2P>, 1024, 0));
+  uint64_t grid = (uint64_t)perCU * (uint64_t)g.prop.multiProcessorCount;
+  // (tests with several ranks on ONE device cap the grid so that all ranks' grids are resident together)
+  if (const char* cap = getenv("SB_VPHASE_MAXGRID")) grid = std::min<uint64_t>(grid, (uint64_t)std::max(1, atoi(cap)));
+  if (grid == 0 || (uint64_t)nSpans > 16ull * grid * SP) return false;
+  s->vSP   = SP;
+  s->vGrid = (uint32_t)std::min<uint64_t>(grid, (nSpans + 16ull * SP - 1) / (16ull * SP));
+  return true;
+}
+static bool vphase_plan(sb_cg* s)
+{
+  if (s->vSP >= 0) return s->vSP > 0;
+  s->vSP = 0;
+  static const bool off    = getenv("SB_VPHASE") && atoi(getenv("SB_VPHASE")) == 0;
+  static const bool shared = getenv("SB_SHARED_GPU") && atoi(getenv("SB_SHARED_GPU")) != 0;
+  if (s->fused < 2 || off || s->nr == 0) return false;
+  if (multi_rank() && (!g.p2pOn || shared)) return false;
+  const uint32_t nSpans = ((s->nr + 255u) >> 8) * 2u;
+  if (multi_rank()) return vphase_try<1, true>(s, nSpans) || vphase_try<2, true>(s, nSpans) || vphase_try<4, true>(s, nSpans);
+  return vphase_try<1, false>(s, nSpans) || vphase_try<2, false>(s, nSpans) || vphase_try<4, false>(s, nSpans);
+}
+int sb_cg_vector_phase(sb_cg* s) { return vphase_plan(s) ? s->vSP : 0; }
+
+static void launch_vphase(sb_cg* s)
+{
+  const long long ticks = 2000ll * P2P_TICKS_PER_MS + (multi_rank() ? g.p2pTimeoutTicks : 0ll);
+  unsigned long long seq = 0;
+  if (multi_rank()) seq = g.p2pSeq + 1ull, g.p2pSeq += 2ull; // two all-reduces per launch
+#define VP_LAUNCH(SPN, PP)                                                                                              \
+  hipLaunchKernelGGL((cg_vector_phase_k<SPN, PP>), dim3(s->vGrid), dim3(1024), 0, g.stream, s->nr, s->r, s->p, s->Ap, s->x, \
+      s->S, s->partials, s->partials2, s->nPartials, s->rr_hist, s->pAp_hist, s->vphase, ticks, (const P2PView*)g.p2pView, seq)
+  if (multi_rank()) {
+    if (s->vSP == 1) VP_LAUNCH(1, true);
+    else if (s->vSP == 2) VP_LAUNCH(2, true);
+    else VP_LAUNCH(4, true);
+  } else {
+    if (s->vSP == 1) VP_LAUNCH(1, false);
+    else if (s->vSP == 2) VP_LAUNCH(2, false);
+    else VP_LAUNCH(4, false);
+  }
+#undef VP_LAUNCH
+  HIP_CHECK(hipGetLastError());
 }
 void sb_cg_set_graph(sb_cg* s, int use_graph) { s->use_graph = use_graph; }
 
@@ -191,6 +254,8 @@ static void loop_body(sb_cg* s, int k)
   if (k == 1) {
     if (n) hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, (double*)nullptr, s->S, 1); // p = r (:109)
     mark(s, R_WAXPBY);
+  } else if (vphase_plan(s)) {
+    // p = r + beta p (:114) was taken at the end of the previous body's vector phase
   } else {
     if (!s->fused) { // rtrans = r.r ; beta (:111-113)
       launch_dot_spans(0, n, s->r, s->r, nullptr, nullptr, s->S, s->partials, stop);
@@ -245,6 +310,10 @@ static void loop_body(sb_cg* s, int k)
     mark(s, R_COMM);
     spmv_event(s);
     spmv_and_pAp(s, stop);
+  }
+  if (vphase_plan(s)) { // alpha | x, r update + r.r | beta, loop test | the next body's p update: one launch
+    launch_vphase(s);
+    return;
   }
   scalar_launch<2>(s);
   mark(s, R_DDOT);
@@ -343,6 +412,13 @@ int sb_cg_finish(sb_cg* s)
   HIP_CHECK(hipStreamSynchronize(g.stream));
   CgScalars h;
   HIP_CHECK(hipMemcpy(&h, s->S, sizeof h, hipMemcpyDeviceToHost));
+  {
+    VPhase vp;
+    HIP_CHECK(hipMemcpy(&vp, s->vphase, sizeof vp, hipMemcpyDeviceToHost));
+    if (vp.error)
+      SB_FATAL("rank %d: the one-launch vector phase timed out waiting for its own workgroups: the GPU is shared with other "
+               "work (set SB_SHARED_GPU=1 or SB_VPHASE=0 to use the separate launches)", g.rank);
+  }
   if (h.p2p_error)
     SB_FATAL("rank %d: a peer's contribution to an in-kernel all-reduce did not arrive within %lld ms "
              "(SB_P2P_TIMEOUT_MS raises the bound, SB_P2P=0 selects the RCCL all-reduce)", g.rank,

@@ -66,6 +66,9 @@ void commInit(Comm* c, int argc, char** argv)
   }
   int local = env_int(localNames, c->rank % ndev);
   sb_init(local % ndev);
+  /* more ranks than devices on this node: ranks share GPUs (a rehearsal).  The one-launch vector phase of the
+   * CG loop needs its grid resident all at once and must not be used then (include/sbhip.h: sb_cg_set_fused) */
+  if (c->size > ndev) setenv("SB_SHARED_GPU", "1", 0);
   if (c->size > 1) {
     unsigned char id[SB_UNIQUE_ID_BYTES];
     char path[512], tmp[544];

@@ -193,9 +193,15 @@ class CG:
         b, xe = problem.rhs()
         self.ptr = self.L.sb_cg_create(problem.matrix, problem.halo, b.ctypes.data_as(vp),
                                        xe.ctypes.data_as(vp) if xe is not None else None)
+        # fused: True = the default (1: dots fused into their producers), False = the reference's op list, or the
+        # level itself (0, 1, 2; 2 = additionally the vector phase as one launch where possible)
         self.L.sb_cg_set_fused(self.ptr, int(fused))
         self.L.sb_cg_set_graph(self.ptr, int(graph))
         self.itermax = 0
+
+    def vector_phase(self):
+        """spans per wave of the one-launch vector phase, 0 if the solver uses the separate launches"""
+        return self.L.sb_cg_vector_phase(self.ptr)
 
     def solve(self, itermax=150, eps=0.0):
         self.itermax = itermax

@@ -40,10 +40,17 @@ def main():
     o = po.cg(locs, plans, itermax=itermax, fmt=fmt, Cc=Cc, sigma=sigma, dot="tree", rank_sum="tree", want_x=True)
     results = {}
     # every kernel the matrix has: SCS C=64 levels 0..3; CRS native (0) and through its pattern mirror (3)
-    for mode in ((3, 2, 1, 0) if fmt == "scs" and Cc == 64 else (3, 0) if fmt == "crs" else (0,)):
+    vphase_seen = 0
+    # (every rank walks the SAME list: what a mode is clamped to may differ from rank to rank, the number of solves must not)
+    for mode in ((5, 3, 2, 1, 0) if fmt == "scs" and Cc == 64 else (5, 3, 0) if fmt == "crs" else (0,)):
         prob.use_packed(mode)  # clamped to what the matrix has
-        for fused in (True, False):
+        # 2: the vector phase as one launch (with the in-kernel all-reduce only; the test caps its grid so that the
+        # grids of all ranks on the one GPU are resident together), 1: five launches per body, 0: reference op list
+        for fused in (2, 1, 0):
             cg = hostapi.CG(prob, fused=fused)
+            vphase_seen += cg.vector_phase() > 0
+            if os.environ.get("SB_TEST_VERBOSE"):
+                print("rank %d: mode %d fused %d vector phase %d" % (rank, mode, fused, cg.vector_phase()), flush=True)
             k = cg.solve(itermax, 0.0)
             rr, pap = cg.history()
             x = cg.solution()
@@ -54,7 +61,7 @@ def main():
             assert np.array_equal(pap, o["pAp"]), ("pAp", mode, fused, rank)
             assert np.array_equal(x, o["x"][rank]), ("x", mode, fused, rank)
             assert err == o["max_err"]
-            results[(mode, fused)] = rr
+            results[(mode, bool(fused))] = rr
     key = "hpcg%d_x%d" % (n, size)
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "cg_hist_mpi.json")))
     if key in golden and golden[key]["itermax"] == itermax:
@@ -63,6 +70,7 @@ def main():
         live = ref / ref[0] >= 1e-20
         assert (np.abs(rr - ref) / ref)[live].max() <= 1e-12  # north_star tolerance vs the MPI reference
     dist.barrier()
+    print("VPHASE_RUNS %d" % vphase_seen, flush=True)
     # the data plane every rank REALLY used (both set-ups are collective decisions: all ranks agree)
     p2p, halo_p2p = L.sb_comm_p2p_enabled(), L.sb_halo_p2p_enabled(prob.halo)
     flags = torch.tensor([p2p, halo_p2p], dtype=torch.int32)

@@ -50,8 +50,9 @@ def test_history_bit_identical_to_oracle_same_dot_order(gpu, fmt, Cc, sigma, n):
     dims = n if isinstance(n, tuple) else (n, n, n)
     g = po.GMatrix.generate(*dims)
     o = po.cg(g, itermax=60, fmt=fmt, Cc=Cc, sigma=sigma, dot="tree", want_x=True)
-    # default kernel choice (small matrices: level 3) and the highest level the matrix has
-    for fused, pack_try in ((True, None), (False, None), (True, 3), (False, 3)):
+    # default kernel choice and the other pattern form the matrix may have (3: row patterns + exception lanes,
+    # 5: masked row programs); fused 2: vector phase as one launch, 1: five launches per body, 0: reference op list
+    for fused, pack_try in ((2, None), (1, None), (0, None), (2, 3), (0, 3), (1, 5)):
         r = run_gpu("generate", n, fmt, Cc, sigma, 60, fused=fused, pack_try=pack_try)
         assert r["k"] == o["k"]
         assert np.array_equal(r["rr"], o["rr"]), (fused, pack_try, "rr")

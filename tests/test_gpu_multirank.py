@@ -38,7 +38,10 @@ def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax, p2p):
     worker reports); p2p=0: local reduce | transport all-reduce | scalar step.  Same bits either way."""
     # p2p=1 (the default set-up): push kernel + SpMV whose halo-touching tiles wait for the flags themselves;
     # p2p=0: transport send-recv, and the two-stream halo overlap (off by default) rides along to keep it covered
-    env = dict(os.environ, OMP_NUM_THREADS="1", SB_P2P=p2p, SB_P2P_REPORT="1", SB_HALO_OVERLAP="1" if p2p == "0" else "0")
+    # SB_VPHASE_MAXGRID: the one-launch vector phase (in-kernel all-reduce only) waits for all of its own workgroups;
+    # with `size` ranks on ONE GPU their grids must be resident together, so each is capped
+    env = dict(os.environ, OMP_NUM_THREADS="1", SB_P2P=p2p, SB_P2P_REPORT="1", SB_HALO_OVERLAP="1" if p2p == "0" else "0",
+               SB_VPHASE_MAXGRID="64")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(size),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "gpu_multirank_worker.py"), fmt, str(Cc), str(sigma), str(n), str(itermax)]
@@ -56,13 +59,16 @@ def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax, p2p):
         if "P2P_ENABLED 1" not in text or "HALO_P2P_ENABLED 1" not in text:
             pytest.skip("peer-mapped path fell back on this box: %s" % why)
         assert any(ln.startswith("P2P_REASON on:") for ln in why) and any(ln.startswith("HALO_P2P_REASON on:") for ln in why), why
+        # ... and so must the one-launch vector phase with the all-reduce inside (where the rank's rows fit the capped grid)
+        if n <= 64:
+            assert "VPHASE_RUNS 0" not in text, text[-2000:]
 
 
 def test_p2p_setup_failure_on_one_rank_falls_back_everywhere(gpu):
     """the in-kernel all-reduce is enabled collectively: if ONE rank cannot export / map its buffer, every
     rank must end up on the transport's all-reduce (no rank may wait in a kernel for a peer that never
     writes), and the run is still bit-exact"""
-    env = dict(os.environ, OMP_NUM_THREADS="1", SB_P2P="1", SB_P2P_FAIL_RANK="1", SB_P2P_REPORT="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", SB_P2P="1", SB_P2P_FAIL_RANK="1", SB_P2P_REPORT="1", SB_VPHASE_MAXGRID="64")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "gpu_multirank_worker.py"), "scs", "64", "1", "16", "60"]

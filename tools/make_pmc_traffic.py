@@ -21,6 +21,8 @@ for spec in sys.argv[3:]:
         name = k.split("<")[0].replace("sbk::", "").strip()
         if not name.startswith("spmv"):
             continue
+        if name == "spmv_scs64_pat" and k.rstrip("> ").endswith("true") and k.count(",") == 4:
+            name = "spmv_scs64_pat_masked"  # <CPT, DOT, SKIPPAD, HALO, MASKED = true>: the level-6 form (bench.py: mode 5)
         e = dict(e, library_version=version, source_tag=tag, kernel_instance=k)
         out.setdefault(workload, {})[name] = e
 path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd)

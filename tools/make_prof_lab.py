@@ -2,7 +2,7 @@
 """make_prof_lab.py -- build labs/libsbhip_prof.so: the product library with per-tile timestamps
 (wall_clock64) in spmv_scs64_pat and an extra entry point sb_lab_prof().  The sources are
 patched in a scratch copy under /tmp; the repository files are not touched.  Read the result
-with:  SBHIP_LIBRARY=labs/libsbhip_prof.so python tools/pat_lab.py 128 256 3"""
+with:  SBHIP_LIBRARY=labs/libsbhip_prof.so python tools/pat_lab.py 128 256 5"""
 import os
 import shutil
 import subprocess
@@ -25,18 +25,19 @@ def patch(path, pairs):
     open(path, "w").write(s)
 
 
+TEMPLATE = ("template <int CPT, bool DOT, bool SKIPPAD, bool HALO, bool MASKED>\n"
+            "__global__ __launch_bounds__(256) void spmv_scs64_pat(")
 patch(W + "/sparsebench_amd/csrc/pack.hip.h", [
-    ("template <bool DOT, bool SKIPPAD, bool HALO>\n__global__ __launch_bounds__(256) void spmv_scs64_pat(",
+    (TEMPLATE,
      "__device__ long long g_prof[8192 * 8];\n"
      "#define PROF(i) do { if (((PROF_POINTS) >> (i)) & 1) if (threadIdx.x == 0 && blockIdx.x < 8192) g_prof[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)\n"
-     "template <bool DOT, bool SKIPPAD, bool HALO>\n__global__ __launch_bounds__(256) void spmv_scs64_pat("),
+     + TEMPLATE),
     ("  // A launch covers headers [firstHdr", "  PROF(0);\n  // A launch covers headers [firstHdr"),
     ("  const int stopped    = (int)field(PAT_STOP_LANE);\n", "  const int stopped    = (int)field(PAT_STOP_LANE);\n  PROF(1);\n"),
     ("  if (tile0 >= nHdrs || stopped) return; // uniform per workgroup\n",
      "  if (tile0 >= nHdrs || stopped) return; // uniform per workgroup\n  PROF(2);\n"),
-    ("mine.off8 + sxOff, mine.m };\n  __syncthreads();\n", "mine.off8 + sxOff, mine.m };\n  __syncthreads();\n  PROF(3);\n"
-     "#ifdef LAB_EXIT_AFTER_BARRIER\n  if (row < nr) y[row] = xrow + (double)base + sx[lane] + se[lane].v;\n  return;\n#endif\n"),
-    ("  if (row < nr) y[row] = acc;\n  if (DOT) {\n    double t2", "  PROF(4);\n  if (row < nr) y[row] = acc;\n  if (DOT) {\n    double t2"),
+    ("mine.off8 + sxOff, mine.m };\n  __syncthreads();\n", "mine.off8 + sxOff, mine.m };\n  __syncthreads();\n  PROF(3);\n"),
+    ("    if (row[c] < nr) y[row[c]] = acc;\n", "    PROF(4 + c);\n    if (row[c] < nr) y[row[c]] = acc;\n"),
 ])
 patch(W + "/sparsebench_amd/csrc/sbhip_matrix.inc.h", [
     ("uint32_t sb_matrix_pattern_classes(const sb_matrix* m) { return pat_of(m)->nPatClasses; }\n",

@@ -39,22 +39,23 @@ for mode in modes:
     print("%s mode %d: %.2f us  (moves %.1f MB)" % (os.environ.get("SBHIP_LIBRARY", "product"), mode, best,
                                                    L.sb_matrix_stream_bytes(m) / 1e6))
 
-# lab build with per-tile timestamps (sb_lab_prof): phases of the pattern kernel, in us
+# lab build with per-tile timestamps (sb_lab_prof): phases of the pattern kernel (the first of `modes`), in us
 if hasattr(L, "sb_lab_prof"):
-    L.sb_matrix_use_packed(m, 3)
+    L.sb_matrix_use_packed(m, modes[0])
     L.sb_spmv_native(m, x.ptr, y.ptr)
     L.sb_spmv_native(m, x.ptr, y.ptr)
     prof = np.zeros(8192 * 8, dtype=np.int64)
     L.sb_lab_prof(prof.ctypes.data_as(C.c_void_p))
-    nT = min(8192, (s.nChunks + 3) // 4)
-    p = prof.reshape(8192, 8)[:nT, :5].astype(np.float64) / 100.0  # wall_clock64: 100 MHz
+    cpt = 8 if s.nChunks > 4 else 4
+    nT = min(8192, (s.nChunks + cpt - 1) // cpt)
+    p = prof.reshape(8192, 8)[:nT, :6].astype(np.float64) / 100.0  # wall_clock64: 100 MHz
     t0 = p[:, 0].min()
-    print("tiles %d; kernel span %.2f us" % (nT, p[:, 4].max() - t0))
-    names = ["start->header", "header->loads back", "loads->barrier passed", "barrier->accumulated"]
+    print("mode %d: tiles %d; kernel span %.2f us" % (L.sb_matrix_packed_mode(m), nT, p[:, 5].max() - t0))
+    names = ["start->header", "header->loads back", "loads->barrier passed", "barrier->chunk 0 summed", "chunk 0->chunk 1 summed"]
     for i, nm in enumerate(names):
         d = p[:, i + 1] - p[:, i]
-        print("  %-24s mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f us" % (nm, d.mean(), *np.percentile(d, [10, 50, 90])))
-    life = p[:, 4] - p[:, 0]
-    print("  tile life                mean %.2f  p50 %.2f  p90 %.2f us" % (life.mean(), *np.percentile(life, [50, 90])))
+        print("  %-26s mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f us" % (nm, d.mean(), *np.percentile(d, [10, 50, 90])))
+    life = p[:, 5] - p[:, 0]
+    print("  tile life                  mean %.2f  p50 %.2f  p90 %.2f us" % (life.mean(), *np.percentile(life, [50, 90])))
     starts = np.sort(p[:, 0] - t0)
     print("  start times: p25 %.2f p50 %.2f p75 %.2f p100 %.2f us" % tuple(np.percentile(starts, [25, 50, 75, 100])))
