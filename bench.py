@@ -353,14 +353,14 @@ def run_rank(args):
         L.sb_sync()
 
     K, W = args.steps, args.warmup
-    vphase = 0
+    vphase, launches = 0, 5
 
     def measure(prob, modes):
         """timed passes on one resident matrix.  modes: kernel modes to time with per-launch events; the
         first is the one `value` is quoted on (clean pass without events)."""
         cg = hostapi.CG(prob, fused=True, graph=bool(args.graph))
-        nonlocal vphase
-        vphase = cg.vector_phase()
+        nonlocal vphase, launches
+        vphase, launches = cg.vector_phase(), cg.launches_per_body()
 
         def timed_pass(with_spmv_events):
             """exactly K loop bodies, in segments restarted from x0 = 0 outside the clock"""
@@ -452,7 +452,7 @@ def run_rank(args):
                            "dot_allreduce_reason": (L.sb_comm_p2p_reason().decode() if world > 1 else None),
                            "halo_exchange_reason": (L.sb_halo_p2p_reason(prob.halo).decode() if world > 1 else None),
                            "spmv_x_staging": ("lds_window" if default >= 2 else "l1_l2_gather (LDS staging measured neutral at 12 B/element)"),
-                           "fused_dots": True, "vector_phase_one_launch": bool(vphase), "launches_per_iteration": 2 if vphase else 5,
+                           "fused_dots": True, "vector_phase_one_launch": bool(vphase), "launches_per_iteration": launches,
                            "hip_graph": bool(args.graph), "library": version},
                 "global_iterations_per_s": it_s,
                 "roofline": roofline_block(kern, d["moved"], d["alg"], d["spmv_us"], d["launches"], *tr),

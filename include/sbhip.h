@@ -209,10 +209,14 @@ void sb_cg_free(sb_cg* s);
  * (alpha | x, r update + r.r | beta, loop test | p update; src/CGSolver.c:124-128 and :107-116) as ONE launch
  * whose workgroups wait for each other -- used when this rank has its GPU to itself (SB_SHARED_GPU=1 says it
  * has not), the all-reduce is the in-kernel one (or there is one rank) and the rows fit the resident grid's
- * registers; otherwise it behaves as 1.  (Measured slower than 1 at 128^3: sbhip_cg.inc.h.)  Same bits in every mode. */
+ * registers; otherwise it behaves as 1; 3: the two scalar steps ride in front of their consumers (workgroup 0 of the
+ * r / p update takes them and publishes alpha / beta through a flag; 3 launches per body; one rank only, otherwise as 1).  (2 and 3 measured slower than 1 at 128^3: sbhip_cg.inc.h.)  Same bits in every mode. */
 void sb_cg_set_fused(sb_cg* s, int fused);
 /* spans per wave of the one-launch vector phase the solver will use, 0 if it will not use it */
 int sb_cg_vector_phase(sb_cg* s);
+/* launches per loop body the loop will use: 5 (p update | SpMV | alpha | r update | beta), 3 (fused = 3), 2 (fused = 2);
+ * 0 for the reference's op list */
+int sb_cg_launches_per_body(sb_cg* s);
 void sb_cg_set_graph(sb_cg* s, int use_graph);
 /* Runs solveCG's whole loop without host synchronisation; returns k exactly as
  * the reference does (src/CGSolver.c:140).  Blocking. */

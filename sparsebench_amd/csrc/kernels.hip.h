@@ -976,6 +976,168 @@ __global__ __launch_bounds__(1024) void cg_vector_phase_k(uint32_t n, double* r,
 }
 
 // =============================================================================
+// Scalar steps inside their consumers ("lead" kernels): 5 -> 3 launches per CG body.
+// (One rank only: with several ranks the combination with the in-kernel all-reduce and the in-SpMV halo wait timed out
+// in the two-ranks-on-one-GPU test and, being slower anyway, was not pursued.)
+// The alpha step (levels 1-2 of p.Ap, alpha = rr / pAp) needs only the partials the SpMV has
+// written, and its only consumers are the kernel that updates r -- so workgroup 0 of THAT kernel takes the step
+// while the other workgroups already have their first loads in flight, then publishes alpha through a flag
+// (agent-scope relaxed atomics, vp_* above) on which the others wait.  The same for the beta step / loop test in
+// front of the p update.  Unlike cg_vector_phase_k nobody waits for ALL workgroups, only for workgroup 0, which is
+// dispatched first: no residency requirement, the reads and writes of the kernel still overlap freely, and the
+// ~4 us of a dependent single-workgroup launch become the ~2 us the reduction itself takes.
+// 1024 threads per workgroup, so that workgroup 0 IS the reduction workgroup of the canonical dot.
+// =============================================================================
+struct Lead { // device control of one lead kernel, zeroed once
+  unsigned long long flag, valueBits, stop;
+  unsigned long long launches; // finished launches: the next one's sequence number - 1
+  int error;
+};
+
+// workgroup 0: total = the finished dot product.  Everybody returns the published (value, stop); false: timeout
+template <int MODE>
+__device__ __forceinline__ bool lead_step(CgScalars* S, const double* __restrict__ partials, uint32_t m,
+    double* __restrict__ rr_hist, double* __restrict__ pAp_hist, Lead* Ld, unsigned long long seq, long long timeoutTicks,
+    double* lds16, double* shVal, int* shFlag, double& value, int& stop)
+{
+  if (blockIdx.x == 0) {
+    const double total = reduce_final_1024(m, partials, lds16);
+    if (threadIdx.x == 0) {
+      cg_apply<MODE>(S, total, rr_hist, pAp_hist, 1);
+      vp_store(&Ld->valueBits, (unsigned long long)__double_as_longlong(MODE == 2 ? S->alpha : S->beta));
+      vp_store(&Ld->stop, (unsigned long long)S->stop);
+      vp_stores_done();
+      vp_store(&Ld->flag, seq);
+      Ld->launches = seq;
+    }
+  }
+  if (threadIdx.x == 0) {
+    const bool ok = vp_wait(&Ld->flag, seq, timeoutTicks);
+    *shVal  = __longlong_as_double((long long)vp_load(&Ld->valueBits));
+    *shFlag = !ok ? 2 : vp_load(&Ld->stop) ? 1 : 0;
+    if (!ok) atomicExch(&Ld->error, 1), S->stop = 1;
+  }
+  __syncthreads();
+  value = *shVal, stop = *shFlag;
+  return *shFlag != 2;
+}
+
+// alpha step + r -= alpha Ap + level-0 partials of r.r   (src/CGSolver.c:124-126, :128, :112)
+// = cg_scalar_k<2> followed by dot_spans_k<3>, element for element
+__global__ __launch_bounds__(1024) void cg_lead_r_k(uint32_t n, const double* __restrict__ Ap, double* r, CgScalars* S,
+    const double* __restrict__ pApPartials, double* __restrict__ rrPartials, uint32_t m, double* __restrict__ rr_hist,
+    double* __restrict__ pAp_hist, Lead* Ld, long long timeoutTicks)
+{
+  __shared__ double lds16[16];
+  __shared__ double shVal;
+  __shared__ int shFlag;
+  const uint32_t lane   = threadIdx.x & 63u;
+  const uint32_t nSpans = ((n + 255u) >> 8) * 2u;
+  const uint32_t nWaves = gridDim.x * (blockDim.x >> 6);
+  uint32_t s            = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // the first two spans' loads go in flight in front of the step
+  const bool pair0 = s + nWaves < nSpans && (s + nWaves) * 128u + 128u <= n; // wave-uniform
+  double2 r0 = { 0.0, 0.0 }, a0 = r0, r1 = r0, a1 = r0;
+  if (pair0) {
+    const uint32_t e0 = s * 128u + lane * 2u, e1 = (s + nWaves) * 128u + lane * 2u;
+    r0 = *reinterpret_cast<const double2*>(r + e0), a0 = *reinterpret_cast<const double2*>(Ap + e0);
+    r1 = *reinterpret_cast<const double2*>(r + e1), a1 = *reinterpret_cast<const double2*>(Ap + e1);
+  }
+  const int stopped            = S->stop;
+  const unsigned long long seq = Ld->launches + 1ull;
+  if (stopped) return;
+  double alpha;
+  int st;
+  if (!lead_step<2>(S, pApPartials, m, rr_hist, pAp_hist, Ld, seq, timeoutTicks, lds16, &shVal, &shFlag, alpha, st)) return;
+  const double nalpha = -alpha;
+  bool have = pair0;
+  while (have) {
+    const uint32_t e0 = s * 128u + lane * 2u, e1 = (s + nWaves) * 128u + lane * 2u;
+    r0.x = r0.x + nalpha * a0.x, r0.y = r0.y + nalpha * a0.y;
+    r1.x = r1.x + nalpha * a1.x, r1.y = r1.y + nalpha * a1.y;
+    *reinterpret_cast<double2*>(r + e0) = r0;
+    *reinterpret_cast<double2*>(r + e1) = r1;
+    const double t0 = butterfly32(r0.x * r0.x + r0.y * r0.y), t1 = butterfly32(r1.x * r1.x + r1.y * r1.y);
+    if ((lane & 31u) == 0) rrPartials[s * 2u + (lane >> 5)] = t0, rrPartials[(s + nWaves) * 2u + (lane >> 5)] = t1;
+    s += 2u * nWaves;
+    have = s + nWaves < nSpans && (s + nWaves) * 128u + 128u <= n;
+    if (have) {
+      const uint32_t f0 = s * 128u + lane * 2u, f1 = (s + nWaves) * 128u + lane * 2u;
+      r0 = *reinterpret_cast<const double2*>(r + f0), a0 = *reinterpret_cast<const double2*>(Ap + f0);
+      r1 = *reinterpret_cast<const double2*>(r + f1), a1 = *reinterpret_cast<const double2*>(Ap + f1);
+    }
+  }
+  for (; s < nSpans; s += nWaves) { // what the paired loop left over
+    const uint32_t e = s * 128u + lane * 2u;
+    double t         = 0.0;
+    if (e + 1 < n) {
+      double2 rv       = *reinterpret_cast<double2*>(r + e);
+      const double2 av = *reinterpret_cast<const double2*>(Ap + e);
+      rv.x = rv.x + nalpha * av.x;
+      rv.y = rv.y + nalpha * av.y;
+      *reinterpret_cast<double2*>(r + e) = rv;
+      t = rv.x * rv.x + rv.y * rv.y;
+    } else if (e < n) {
+      const double rn = r[e] + nalpha * Ap[e];
+      r[e]            = rn;
+      t               = rn * rn + 0.0;
+    }
+    t = butterfly32(t);
+    if ((lane & 31u) == 0) rrPartials[s * 2u + (lane >> 5)] = t;
+  }
+}
+
+// beta step / loop test + p = r + beta p + the x update the previous body owes   (:107-116, :127)
+// = cg_scalar_k<1> (defer_x) followed by cg_update_p(which = 0, x), element for element
+__global__ __launch_bounds__(1024) void cg_lead_p_k(uint32_t n, const double* __restrict__ r, double* p, double* x,
+    CgScalars* S, const double* __restrict__ rrPartials, uint32_t m, double* __restrict__ rr_hist,
+    double* __restrict__ pAp_hist, Lead* Ld, long long timeoutTicks)
+{
+  __shared__ double lds16[16];
+  __shared__ double shVal;
+  __shared__ int shFlag;
+  const uint32_t n2     = n >> 1;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const double2* r2     = reinterpret_cast<const double2*>(r);
+  double2* p2           = reinterpret_cast<double2*>(p);
+  double2* x2           = reinterpret_cast<double2*>(x);
+  uint32_t i            = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t last   = n2 ? n2 - 1u : 0u;
+  double2 a0 = { 0.0, 0.0 }, b0 = a0, x0 = a0, a1 = a0, b1 = a0, x1 = a0;
+  auto load = [&](uint32_t j, double2& a, double2& b, double2& xv) { a = r2[j], b = p2[j], xv = x2[j]; };
+  if (n2) load(min(i, last), a0, b0, x0), load(min(i + stride, last), a1, b1, x1);
+  const int stopped            = S->stop;
+  const double alpha           = S->alpha; // of the previous body: written by the kernel before this one
+  const unsigned long long seq = Ld->launches + 1ull;
+  if (stopped) return;
+  double beta;
+  int st;
+  if (!lead_step<1>(S, rrPartials, m, rr_hist, pAp_hist, Ld, seq, timeoutTicks, lds16, &shVal, &shFlag, beta, st)) return;
+  if (st) return; // the loop has ended: p stays, the x update stays owed (cg_x_finalize)
+  auto finish = [&](uint32_t j, const double2& a, const double2& b, double2 xv) {
+    xv.x = xv.x + alpha * b.x;
+    xv.y = xv.y + alpha * b.y;
+    x2[j] = xv;
+    double2 o;
+    o.x = a.x + beta * b.x;
+    o.y = a.y + beta * b.y;
+    p2[j] = o;
+  };
+  for (; i < n2; i += 2u * stride) {
+    const bool second = i + stride < n2;
+    finish(i, a0, b0, x0);
+    if (second) finish(i + stride, a1, b1, x1);
+    const uint32_t nx = i + 2u * stride;
+    if (nx < n2) load(nx, a0, b0, x0), load(min(nx + stride, last), a1, b1, x1);
+  }
+  if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double bb = p[n - 1];
+    x[n - 1]        = x[n - 1] + alpha * bb;
+    p[n - 1]        = r[n - 1] + beta * bb;
+  }
+}
+
+// =============================================================================
 // permutation / halo helpers
 // =============================================================================
 __global__ __launch_bounds__(256) void gather_k(uint32_t n, const uint32_t* __restrict__ idx,

@@ -277,6 +277,10 @@ struct sb_cg {
   double* partials2 = nullptr; // level-0 partials of r.r (the p.Ap ones stay in `partials` while it reads them)
   int vSP = -1;                // spans per wave of the chosen instantiation; 0: not eligible; -1: not planned yet
   uint32_t vGrid = 0;
+  // fused >= 1: the scalar steps inside their consumers (kernels.hip.h: cg_lead_r_k / cg_lead_p_k), 3 launches per body
+  Lead* lead     = nullptr; // [0] alpha step, [1] beta step
+  int leadPlan   = -1;      // 1 in use, 0 not, -1 not decided yet
+  bool betaOwed  = false;   // the last enqueued body's beta step / loop test has not been enqueued yet
 };
 
 // ===========================================================================

@@ -914,11 +914,12 @@ static void build_patterns(sb_matrix* m, const uint32_t* chunkPtr, const uint32_
   const size_t nSegs = pattern_headers(m, P, &m->tileHdrs);
   m->patBytes = (double)P.words * 4.0 + 16.0 * (double)P.excEntries + 2.0 * 64.0 * m->nChunks + 16.0 * nSegs +
                 (double)(P.cpt == 8 ? 384 : 192) * P.nTiles + (P.anyL ? 4096.0 * P.classes.size() : 0.0) + 16.0 * P.rowPats.size();
-  // Default kernel: the pattern kernel once the matrix is more than one round of resident
-  // workgroups (8 per CU, 4 chunks each); below that everything is one dependent-latency chain and the
-  // level-3 kernel's is shorter (64^3: 46.7k vs 43.2k CG it/s; 96^3: 22.8k vs 26.3k).
-  // sb_matrix_use_packed(m, 3) selects it regardless.
-  m->usePacked = (m->nChunks + 3) / 4 > (uint32_t)g.prop.multiProcessorCount * 8u ? (m->mHdrs ? 5 : 3) : 2;
+  // Default kernel: the masked row programs wherever they were built (round 2, stand-alone launches: 64^3 5.6 us against
+  // 6.4 us for level 3 and 7.7 us for level 5; 96^3 10.0 / 18.5 / 15.8; 128^3 18.6 / - / 27.5).  Otherwise the level-5
+  // kernel once the matrix is more than one round of resident workgroups (8 per CU, 4 chunks each); below that
+  // everything is one dependent-latency chain and the level-3 kernel's is shorter (64^3: 46.7k vs 43.2k CG it/s;
+  // 96^3: 22.8k vs 26.3k).  sb_matrix_use_packed(m, 3) selects it regardless.
+  m->usePacked = m->mHdrs ? 5 : (m->nChunks + 3) / 4 > (uint32_t)g.prop.multiProcessorCount * 8u ? 3 : 2;
 }
 
 sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, uint32_t nChunks,

@@ -203,6 +203,9 @@ class CG:
         """spans per wave of the one-launch vector phase, 0 if the solver uses the separate launches"""
         return self.L.sb_cg_vector_phase(self.ptr)
 
+    def launches_per_body(self):
+        return self.L.sb_cg_launches_per_body(self.ptr)
+
     def solve(self, itermax=150, eps=0.0):
         self.itermax = itermax
         return self.L.sb_cg_solve(self.ptr, itermax, eps)

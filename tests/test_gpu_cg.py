@@ -51,14 +51,51 @@ def test_history_bit_identical_to_oracle_same_dot_order(gpu, fmt, Cc, sigma, n):
     g = po.GMatrix.generate(*dims)
     o = po.cg(g, itermax=60, fmt=fmt, Cc=Cc, sigma=sigma, dot="tree", want_x=True)
     # default kernel choice and the other pattern form the matrix may have (3: row patterns + exception lanes,
-    # 5: masked row programs); fused 2: vector phase as one launch, 1: five launches per body, 0: reference op list
-    for fused, pack_try in ((2, None), (1, None), (0, None), (2, 3), (0, 3), (1, 5)):
+    # 5: masked row programs); fused 1: five launches per body, 2: vector phase as one launch, 3: scalar steps inside their consumers, 0: reference op list
+    for fused, pack_try in ((1, None), (2, None), (3, None), (0, None), (3, 3), (0, 3), (1, 5)):
         r = run_gpu("generate", n, fmt, Cc, sigma, 60, fused=fused, pack_try=pack_try)
         assert r["k"] == o["k"]
         assert np.array_equal(r["rr"], o["rr"]), (fused, pack_try, "rr")
         assert np.array_equal(r["pAp"], o["pAp"]), (fused, pack_try, "pAp")
         assert np.array_equal(r["x"], o["x"][0]), (fused, pack_try, "x")
         assert r["err"] == o["max_err"]
+
+
+def test_launches_per_body_variants(gpu):
+    """fused = 1 (default): five launches per body; 3: the two scalar steps ride in front of their consumers (3 launches);
+    2: the one-launch vector phase (2); 0: the reference's op list.  Same bits in all of them, also when the loop is
+    driven in pieces (every run_iters call flushes an owed beta step) and when it ends early (eps)."""
+    g = po.GMatrix.generate(24, 20, 16)
+    o = po.cg(g, itermax=70, fmt="scs", Cc=64, sigma=1, dot="tree", want_x=True)
+    oe = po.cg(g, itermax=70, eps=1e-4, fmt="scs", Cc=64, sigma=1, dot="tree", want_x=True)
+    assert oe["k"] < o["k"]
+    for fused, want in ((1, 5), (3, 3), (2, 2), (0, 0)):
+        p = hostapi.Problem("generate", 24, 20, 16, fmt="scs", Cc=64, sigma=1)
+        cg = hostapi.CG(p, fused=fused)
+        assert cg.launches_per_body() == want
+        assert cg.solve(70, 0.0) == o["k"]
+        rr, pap = cg.history()
+        assert np.array_equal(rr, o["rr"]) and np.array_equal(pap, o["pAp"]) and np.array_equal(cg.solution(), o["x"][0])
+        # in pieces: the loop state is complete after every piece
+        cg.start(70, 0.0)
+        done = 0
+        for piece in (1, 1, 5, 30, 32):
+            cg.run_iters(piece)
+            done += piece
+            c = cg.counters()
+            assert c["n_pAp"] == done, (c, done, fused)
+            if fused:  # (the reference's op list takes the loop test at the START of the next body)
+                last = done == 69  # the 69th body's loop test fails (k = 70 = itermax): no further r.r, stop raised
+                assert c["iters"] == (69 if last else done + 1) and c["n_rr"] == (69 if last else done + 1), (c, done, fused)
+                assert c["stop"] == int(last), (c, done, fused)
+        assert cg.finish() == o["k"]
+        rr, pap = cg.history()
+        assert np.array_equal(rr, o["rr"]) and np.array_equal(pap, o["pAp"]) and np.array_equal(cg.solution(), o["x"][0])
+        # early exit through eps: the bodies enqueued behind the exit do nothing
+        assert cg.solve(70, 1e-4) == oe["k"]
+        rr, pap = cg.history()
+        assert np.array_equal(rr, oe["rr"]) and np.array_equal(pap, oe["pAp"]) and np.array_equal(cg.solution(), oe["x"][0])
+        cg.free(), p.free()
 
 
 def test_graph_replay_gives_the_same_bits(gpu):
