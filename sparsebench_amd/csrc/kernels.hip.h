@@ -91,12 +91,24 @@ __device__ __forceinline__ double level1(const double* __restrict__ q, uint32_t 
   return ((a.x + a.y) + b.x) + b.y;
 }
 
-// m = number of level-1 values = ceil(n/256); q holds 4*m level-0 partials
+// m = number of level-1 values = ceil(n/256); q holds 4*m level-0 partials -- or, l1 != 0, the m level-1 values
+// themselves (a producer whose waves own whole 256-groups forms them in registers: cg_update_r_k; the single CU
+// that runs this reduction then moves a quarter of the bytes through its one vector-memory pipe)
 __device__ __forceinline__ double reduce_final_1024(uint32_t m, const double* __restrict__ q,
-    double* lds16)
+    double* lds16, int l1 = 0)
 {
   double s   = 0.0;
   uint32_t i = threadIdx.x;
+  if (l1) {
+    for (; i + 7u * 1024u < m; i += 8u * 1024u) {
+      double a[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) a[u] = q[i + (uint32_t)u * 1024u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s = s + a[u];
+    }
+    for (; i < m; i += 1024u) s = s + q[i];
+  } else {
   for (; i + 7u * 1024u < m; i += 8u * 1024u) { // 16 independent 16-B loads in flight
     double a[8];
 #pragma unroll
@@ -105,6 +117,7 @@ __device__ __forceinline__ double reduce_final_1024(uint32_t m, const double* __
     for (int u = 0; u < 8; u++) s = s + a[u];
   }
   for (; i < m; i += 1024u) s = s + level1(q, i);
+  }
   s = butterfly64(s);
   if ((threadIdx.x & 63u) == 0) lds16[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -117,28 +130,30 @@ __device__ __forceinline__ double reduce_final_1024(uint32_t m, const double* __
 // The scalar steps of solveCG.  MODE 0: r.r of the prologue (src/CGSolver.c:98-103) and the
 // loop test for k = 1.  MODE 1: the loop test for the next k (:107), and if it passes
 // the r.r / beta of that iteration (:111-113,:116).  MODE 2: p.Ap -> alpha (:124-126).
+// `in`: the control block as it was when the kernel started (thread 0 fetches it next to the partial loads, so that
+// the step does not begin with a second, dependent round trip to memory); only the changed fields are stored.
 template <int MODE>
-__device__ __forceinline__ void cg_apply(CgScalars* S, double total, double* rr_hist,
+__device__ __forceinline__ void cg_apply(CgScalars* S, const CgScalars& in, double total, double* rr_hist,
     double* pAp_hist, int defer_x)
 {
   if (MODE == 0) {
-    const int sn = !(sqrt(total) > S->eps);
+    const int sn = !(sqrt(total) > in.eps);
     S->rr        = total;
     S->stop_next = sn;
-    if (S->n_rr < S->hist_cap) rr_hist[S->n_rr] = total;
-    S->n_rr++;
-    if (1 < S->itermax && !sn) S->iters = 1;
+    if (in.n_rr < in.hist_cap) rr_hist[in.n_rr] = total;
+    S->n_rr = in.n_rr + 1;
+    if (1 < in.itermax && !sn) S->iters = 1;
     else S->stop = 1;
   } else if (MODE == 1) {
-    if (S->iters + 1 < S->itermax && !S->stop_next) {
-      const double old = S->rr;
+    if (in.iters + 1 < in.itermax && !in.stop_next) {
+      const double old = in.rr;
       S->rr_old        = old;
       S->rr            = total;
       S->beta          = total / old;
-      S->stop_next     = !(sqrt(total) > S->eps);
-      S->iters         = S->iters + 1;
-      if (S->n_rr < S->hist_cap) rr_hist[S->n_rr] = total;
-      S->n_rr++;
+      S->stop_next     = !(sqrt(total) > in.eps);
+      S->iters         = in.iters + 1;
+      if (in.n_rr < in.hist_cap) rr_hist[in.n_rr] = total;
+      S->n_rr = in.n_rr + 1;
     } else {
       S->stop = 1;
     }
@@ -146,12 +161,26 @@ __device__ __forceinline__ void cg_apply(CgScalars* S, double total, double* rr_
   } else {
     S->x_pending    = 0; // consumed by the p update that preceded this SpMV
     S->pAp          = total;
-    const double al = S->rr / total;
+    const double al = in.rr / total;
     S->alpha        = al;
     S->neg_alpha    = -al;
-    if (S->n_pAp < S->hist_cap) pAp_hist[S->n_pAp] = total;
-    S->n_pAp++;
+    if (in.n_pAp < in.hist_cap) pAp_hist[in.n_pAp] = total;
+    S->n_pAp = in.n_pAp + 1;
   }
+}
+template <int MODE>
+__device__ __forceinline__ void cg_apply(CgScalars* S, double total, double* rr_hist, double* pAp_hist, int defer_x)
+{
+  const CgScalars in = *S;
+  cg_apply<MODE>(S, in, total, rr_hist, pAp_hist, defer_x);
+}
+// the control block into registers, pinned in front of whatever follows
+__device__ __forceinline__ CgScalars cg_fetch(const CgScalars* S)
+{
+  const CgScalars in = *S;
+  asm volatile("" ::"v"(in.rr), "v"(in.eps), "v"(in.stop), "v"(in.stop_next), "v"(in.iters), "v"(in.n_rr), "v"(in.n_pAp),
+      "v"(in.itermax), "v"(in.hist_cap));
+  return in;
 }
 
 // SpMV epilogue: y store and, when DOT, the chunk's level-0 partial of p.Ap (a chunk IS a
@@ -559,6 +588,73 @@ __global__ __launch_bounds__(256) void dot_spans_k(uint32_t n, const double* a, 
   }
 }
 
+// r -= alpha Ap and r.r of the fused loop (src/CGSolver.c:128 + :112), once per CG iteration.  A wave owns whole
+// 256-groups (two adjacent spans), so it forms the group's LEVEL-1 value ((q0 + q1) + q2) + q3 in registers and the
+// scalar step that follows reads n/256 doubles instead of n/64 (reduce_final_1024, l1).  The first group's loads go
+// in flight together with the stop flag / alpha instead of behind them.  Same arithmetic, same order, same bits as
+// dot_spans_k<3> + level1().
+__global__ __launch_bounds__(256) void cg_update_r_k(uint32_t n, const double* __restrict__ Ap, double* r,
+    const CgScalars* __restrict__ S, double* __restrict__ l1out, const int* __restrict__ stop)
+{
+  const uint32_t lane    = threadIdx.x & 63u;
+  const uint32_t nGroups = (n + 255u) >> 8;
+  const uint32_t nWaves  = gridDim.x * (blockDim.x >> 6);
+  uint32_t gI            = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  auto full = [&](uint32_t gg) { return gg < nGroups && gg * 256u + 256u <= n; }; // wave-uniform
+  double2 r0 = { 0.0, 0.0 }, a0 = r0, r1 = r0, a1 = r0;
+  bool have  = full(gI);
+  if (have) {
+    const uint32_t e0 = gI * 256u + lane * 2u, e1 = e0 + 128u;
+    r0 = *reinterpret_cast<const double2*>(r + e0), a0 = *reinterpret_cast<const double2*>(Ap + e0);
+    r1 = *reinterpret_cast<const double2*>(r + e1), a1 = *reinterpret_cast<const double2*>(Ap + e1);
+  }
+  if (stop && *stop) return;
+  const double nalpha = -S->alpha;
+  auto combine = [&](double t0, double t1) { // halves of t0: q0, q1; of t1: q2, q3
+    const double q0 = __shfl(t0, 0, 64), q1 = __shfl(t0, 32, 64), q2 = __shfl(t1, 0, 64), q3 = __shfl(t1, 32, 64);
+    return ((q0 + q1) + q2) + q3;
+  };
+  while (have) {
+    const uint32_t e0 = gI * 256u + lane * 2u, e1 = e0 + 128u;
+    r0.x = r0.x + nalpha * a0.x, r0.y = r0.y + nalpha * a0.y;
+    r1.x = r1.x + nalpha * a1.x, r1.y = r1.y + nalpha * a1.y;
+    *reinterpret_cast<double2*>(r + e0) = r0;
+    *reinterpret_cast<double2*>(r + e1) = r1;
+    const double v = combine(butterfly32(r0.x * r0.x + r0.y * r0.y), butterfly32(r1.x * r1.x + r1.y * r1.y));
+    if (lane == 0) l1out[gI] = v;
+    gI += nWaves;
+    have = full(gI);
+    if (have) {
+      const uint32_t f0 = gI * 256u + lane * 2u, f1 = f0 + 128u;
+      r0 = *reinterpret_cast<const double2*>(r + f0), a0 = *reinterpret_cast<const double2*>(Ap + f0);
+      r1 = *reinterpret_cast<const double2*>(r + f1), a1 = *reinterpret_cast<const double2*>(Ap + f1);
+    }
+  }
+  for (; gI < nGroups; gI += nWaves) { // the last, partial group
+    double t[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const uint32_t e = gI * 256u + (uint32_t)h * 128u + lane * 2u;
+      double tt        = 0.0;
+      if (e + 1 < n) {
+        double2 rv       = *reinterpret_cast<double2*>(r + e);
+        const double2 av = *reinterpret_cast<const double2*>(Ap + e);
+        rv.x = rv.x + nalpha * av.x;
+        rv.y = rv.y + nalpha * av.y;
+        *reinterpret_cast<double2*>(r + e) = rv;
+        tt = rv.x * rv.x + rv.y * rv.y;
+      } else if (e < n) {
+        const double rn = r[e] + nalpha * Ap[e];
+        r[e]            = rn;
+        tt              = rn * rn + 0.0;
+      }
+      t[h] = butterfly32(tt);
+    }
+    const double v = combine(t[0], t[1]);
+    if (lane == 0) l1out[gI] = v;
+  }
+}
+
 // stand-alone level 2 (sb_reduce_final / unfused path)
 __global__ __launch_bounds__(1024) void reduce_final_k(uint32_t m, const double* __restrict__ q,
     double* __restrict__ out, const int* __restrict__ stop)
@@ -732,27 +828,27 @@ __global__ __launch_bounds__(256) void halo_pull_k(const int* __restrict__ srcRa
 // all-reduce on several ranks (REDUCE = false: the sum is already in S->local).
 template <int MODE, bool REDUCE>
 __global__ __launch_bounds__(1024) void cg_scalar_k(uint32_t m, const double* __restrict__ q,
-    CgScalars* S, double* __restrict__ rr_hist, double* __restrict__ pAp_hist, int to_local, int defer_x)
+    CgScalars* S, double* __restrict__ rr_hist, double* __restrict__ pAp_hist, int to_local, int defer_x, int l1)
 {
   __shared__ double lds16[16];
-  // This launch sits on the critical path of every iteration: do not serialise the flag's
-  // round trip in front of the partial loads -- read it, reduce (harmless if the loop has
+  // This launch sits on the critical path of every iteration: do not serialise the control block's
+  // round trip in front of the partial loads -- fetch it, reduce (harmless if the loop has
   // already exited), and only then branch on it.
-  const int stopped = S->stop;
+  const CgScalars in = cg_fetch(S);
+  const int stopped  = in.stop;
   double total;
   if (REDUCE) {
-    total = reduce_final_1024(m, q, lds16);
+    total = reduce_final_1024(m, q, lds16, l1);
     if (stopped) return;
     if (to_local) {
       if (threadIdx.x == 0) S->local = total;
       return;
     }
   } else {
-    total = S->local;
+    total = in.local;
     if (stopped) return;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) cg_apply<MODE>(S, total, rr_hist, pAp_hist, defer_x);
+  if (threadIdx.x == 0) cg_apply<MODE>(S, in, total, rr_hist, pAp_hist, defer_x);
 }
 
 // The same step on several ranks with the all-reduce inside (p2p_allreduce_sum): local levels
@@ -760,20 +856,21 @@ __global__ __launch_bounds__(1024) void cg_scalar_k(uint32_t m, const double* __
 template <int MODE>
 __global__ __launch_bounds__(1024) void cg_scalar_p2p_k(uint32_t m, const double* __restrict__ q,
     CgScalars* S, double* __restrict__ rr_hist, double* __restrict__ pAp_hist, int defer_x,
-    const P2PView* __restrict__ pv, unsigned long long seq)
+    const P2PView* __restrict__ pv, unsigned long long seq, int l1)
 {
   __shared__ double lds16[16];
-  const int stopped = S->stop; // identical on every rank: all of them skip the exchange, or none
-  double total      = reduce_final_1024(m, q, lds16);
+  const CgScalars in = cg_fetch(S);
+  const int stopped  = in.stop; // identical on every rank: all of them skip the exchange, or none
+  double total       = reduce_final_1024(m, q, lds16, l1);
   if (stopped) return;
   __syncthreads(); // lds16 is reused
   total = p2p_allreduce_sum(pv, total, seq, lds16, &S->p2p_error);
-  // (atomic load: the line holding p2p_error was read for S->stop above, a plain load could be served stale)
+  // (atomic load: the line holding p2p_error was read with the control block above, a plain load could be served stale)
   if (__hip_atomic_load(&S->p2p_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // uniform: raised before the barriers inside the exchange
     if (threadIdx.x == 0) S->stop = 1;
     return;
   }
-  if (threadIdx.x == 0) cg_apply<MODE>(S, total, rr_hist, pAp_hist, defer_x);
+  if (threadIdx.x == 0) cg_apply<MODE>(S, in, total, rr_hist, pAp_hist, defer_x);
 }
 
 // =============================================================================

@@ -137,7 +137,7 @@ static bool vphase_plan(sb_cg* s)
 }
 int sb_cg_vector_phase(sb_cg* s) { return vphase_plan(s) ? s->vSP : 0; }
 
-template <int MODE> static void scalar_launch(sb_cg* s, int defer_x, const double* q);
+template <int MODE> static void scalar_launch(sb_cg* s, int defer_x, const double* q, int l1 = 0);
 
 // The scalar steps inside their consumers (sb_cg_set_fused(s, 3)): one rank only.
 // Measured (MI355X, HPCG 128^3, Sell-64-256, same box, back to back): 58.6 us per iteration against 51.7 us with the
@@ -242,24 +242,25 @@ static bool spmv_can_fuse_dot(const sb_cg* s)
 // levels 1-2 of the reduction + the scalar step: one 1-workgroup launch after the producer
 // (several ranks: local sum -> RCCL all-reduce in place on the stream -> scalar step;
 // MPI_Allreduce of src/comm.c:659)
-template <int MODE> static void scalar_launch(sb_cg* s, int defer_x, const double* q)
+// l1: q holds level-1 values (cg_update_r_k) instead of level-0 partials
+template <int MODE> static void scalar_launch(sb_cg* s, int defer_x, const double* q, int l1)
 {
   if (!q) q = s->partials;
   if (multi_rank() && g.p2pOn) { // local reduce, in-kernel all-reduce and scalar step in ONE launch
     hipLaunchKernelGGL((cg_scalar_p2p_k<MODE>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, q,
-        s->S, s->rr_hist, s->pAp_hist, defer_x, (const P2PView*)g.p2pView, ++g.p2pSeq);
+        s->S, s->rr_hist, s->pAp_hist, defer_x, (const P2PView*)g.p2pView, ++g.p2pSeq, l1);
     HIP_CHECK(hipGetLastError());
     return;
   }
   hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, q,
-      s->S, s->rr_hist, s->pAp_hist, multi_rank() ? 1 : 0, defer_x);
+      s->S, s->rr_hist, s->pAp_hist, multi_rank() ? 1 : 0, defer_x, l1);
   HIP_CHECK(hipGetLastError());
   if (multi_rank()) {
     mark(s, R_DDOT);
     sb_comm_reduction(&s->S->local, 1);
     mark(s, R_COMM);
     hipLaunchKernelGGL((cg_scalar_k<MODE, false>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, q,
-        s->S, s->rr_hist, s->pAp_hist, 0, defer_x);
+        s->S, s->rr_hist, s->pAp_hist, 0, defer_x, 0);
     HIP_CHECK(hipGetLastError());
   }
 }
@@ -374,9 +375,12 @@ static void loop_body(sb_cg* s, int k)
   scalar_launch<2>(s, 0, nullptr);
   mark(s, R_DDOT);
   if (s->fused) { // r -= alpha Ap (:128) + next r.r, beta, loop test; x += alpha p (:127) is owed
-    launch_dot_spans(3, n, s->p, s->Ap, s->x, s->r, s->S, s->partials, stop);
+    // (level-1 values of r.r into partials2: `partials` keeps the layout the p.Ap producers write)
+    hipLaunchKernelGGL(cg_update_r_k, dim3(stream_grid((n + 255u) >> 8, 4)), dim3(256), 0, g.stream, n, s->Ap, s->r, s->S,
+        s->partials2, stop);
+    HIP_CHECK(hipGetLastError());
     mark(s, R_WAXPBY);
-    scalar_launch<1>(s, 1, nullptr);
+    scalar_launch<1>(s, 1, s->partials2, 1);
     mark(s, R_DDOT);
   } else if (n) {
     hipLaunchKernelGGL(waxpby_sdev_k, gridV, blockV, 0, g.stream, n, s->x, &s->S->alpha, s->p, s->x, stop);
