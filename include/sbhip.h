@@ -87,11 +87,12 @@ int sb_matrix_pack_level(const sb_matrix* m);
  * gathered through the cache, 2 packed stream with each workgroup's x window staged in LDS
  * (built when every tile's window fits; SB_PACK=2 stops at mode 1), 3 one-byte pattern
  * codes naming (value, window-slot delta) pairs + LDS window (built when every tile has
- * <= 255 distinct pairs; SB_PACK=3 stops at mode 2).  Clamped to what the matrix has;
- * default = the highest available, except that matrices of at most one round of resident
- * workgroups (8 tiles of 256 rows per CU) default to mode 2, which is faster there.  All modes give
- * bit-identical results. */
-/* CRS matrices: 0 = native CRS kernel, 3 = product through a device-private Sell-64-1 pattern mirror whose
+ * <= 255 distinct pairs; SB_PACK=3 stops at mode 2), 5 the same tiles with every chunk stored as a
+ * masked row program (built when >= 98 % of the chunks' rows are sub-sequences of a row of their tile;
+ * SB_PACK=5 stops at mode 3; there is no mode 4).  Clamped to what the matrix has: a mode it lacks
+ * falls to the next lower one.  Default = 5 where built, else 3 for matrices of more than one round of
+ * resident workgroups (8 tiles of 256 rows per CU) and 2 below that.  All modes give bit-identical results. */
+/* CRS matrices: 0 = native CRS kernel, 3 / 5 = product through a device-private Sell-64-1 pattern mirror whose
  * padding is not added (exactly the CRS loop's sums); built when the matrix has repeating row patterns. */
 void sb_matrix_use_packed(sb_matrix* m, int mode);
 int sb_matrix_packed_mode(const sb_matrix* m);
