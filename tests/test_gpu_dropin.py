@@ -164,12 +164,14 @@ def test_run_benchmarks_executable(gpu, fmt, inp):
     rows = {m.group(1): [float(v) for v in m.group(2).split()] for m in re.finditer(r"^(spMVM|waxpby|ddot)\s+([0-9][0-9. ]*)$", txt, re.M)}
     assert set(rows) == {"spMVM", "waxpby", "ddot"}, txt
     for name, (us, gbs_alg, gbs_ref, gflops) in rows.items():
-        assert us > 0 and gbs_alg > 0 and gflops >= 0, (name, us)  # (%.1f of a 100-row dot rounds to 0.0)
+        assert us > 0 and gbs_alg >= 0 and gflops >= 0, (name, us)  # (%.1f of a 100-row kernel can round to 0.0)
     prob = hostapi.Problem(pa[0], pa[1], pa[2], pa[3], fmt=fmt.lower(), Cc=64, sigma=32)
     alg = prob.spmv_bytes()
     m = re.search(r"spMVM moves ([0-9.]+) MB per launch \(reference layout: ([0-9.]+) MB", txt)
     assert m and abs(float(m.group(2)) - alg / 1e6) <= 0.051, (m and m.group(0), alg)
     us, gbs_alg = rows["spMVM"][0], rows["spMVM"][1]
     assert abs(gbs_alg - alg / (us * 1e-6) / 1e9) <= 0.02 * gbs_alg + 0.1  # rate = those bytes / the printed time
+    if inp == "hpcg32":
+        assert us < 200.0, us  # (a 32^3 product takes ~5 us; a first-touch stall once showed up as 4 ms per call on the 100-row case)
     assert re.search(r"rows %d  stored nonzeros %d " % (prob.nr, prob.nnzTrue), txt), txt
     prob.free()
