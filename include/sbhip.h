@@ -82,6 +82,12 @@ double sb_matrix_spmv_bytes(const sb_matrix* m);
  * (csrc/pack.hip.h; SB_PACK=0 disables it): level 1 = 16-bit column offsets per chunk,
  * level 2 = additionally a <=256-entry value dictionary.  Results are bit-identical to
  * the uncompressed kernel; the host-visible arrays keep the reference layout. */
+/* Optional, before an upload of a rank-local matrix: the global ids of its halo columns (local column nr + i has
+ * global id global_ids[i]; commPartition's Comm::externalGlobal).  Used only to lay out device-private x windows
+ * (the partitioner numbers halo columns in the order it met them; in ascending global order a stencil's halo
+ * plane looks like the rank's own planes and the pattern levels apply to the tiles next to a rank boundary).
+ * Stays in force until replaced (n = 0 clears); uploads whose nc - nr differs from n ignore it. */
+void sb_set_external_ids(const uint32_t* global_ids, uint32_t n);
 int sb_matrix_pack_level(const sb_matrix* m);
 /* select the SpMV kernel at run time: 0 reference-layout stream, 1 packed stream with x
  * gathered through the cache, 2 packed stream with each workgroup's x window staged in LDS

@@ -218,6 +218,7 @@ struct sb_matrix {
   TileSeg* mSegs       = nullptr; // (mOwnsTables) when the windows are laid out in original column order
   uint16_t* mSlotMap   = nullptr; // ... then: [tile][mMapStride] slot -> device column - the 256-slot block's base
   uint32_t mWindow = 0, mMapStride = 0;
+  uint32_t mCPT = 4, mNTiles = 0, mInterior = 0; // its own tile shape (level 5 may have had to take the smaller one)
   bool mOwnsTables = false;
   double mBytes  = 0.0;
   // CRS: a private Sell-64-1 mirror carrying only the pattern levels (SKIPPAD kernel); usePacked
@@ -227,6 +228,9 @@ struct sb_matrix {
   uint32_t nPatClasses  = 0;
   double patBytes       = 0.0;
 };
+
+// global ids of the halo columns of the matrix about to be uploaded (sb_set_external_ids); consumed by the next upload
+static std::vector<uint32_t> g_externalIds;
 
 struct sb_halo {
   uint32_t nr;

@@ -16,7 +16,9 @@ static bool spmv_uses_patterns(const sb_matrix* m)
 static bool spmv_can_split(const sb_matrix* m)
 {
   const sb_matrix* pm = pat_of(m);
-  return spmv_uses_patterns(m) && pm->patInterior > 0 && pm->patInterior < pm->patNTiles;
+  if (!spmv_uses_patterns(m)) return false;
+  if (m->usePacked == 5) return pm->mInterior > 0 && pm->mInterior < pm->mNTiles;
+  return pm->patInterior > 0 && pm->patInterior < pm->patNTiles;
 }
 static void launch_pat(const sb_matrix* pm, bool skipPad, bool masked, const double* x, double* y, double* dotPartials,
     const int* stop, int part, hipStream_t stream, const HaloWait* halo);
@@ -112,12 +114,12 @@ static void launch_pat(const sb_matrix* pm, bool skipPad, bool masked, const dou
   if (halo) hw = *halo;
   if (masked && !pm->mHdrs) SB_FATAL("the matrix has no masked row programs");
   const bool dot         = dotPartials != nullptr;
-  const uint32_t nBlocks = pm->patNTiles;
+  const uint32_t nBlocks = masked ? pm->mNTiles : pm->patNTiles, interior = masked ? pm->mInterior : pm->patInterior;
   const uint32_t dictE = masked ? pm->mDict : pm->patDict, excE = masked ? 0u : pm->patExcLds;
   const size_t shmem = ((size_t)dictE + excE + 8) * sizeof(PatEntry) + (size_t)(masked ? pm->mWindow : pm->patWindow) * sizeof(double);
   if (!stop) stop = zero_flag();
-  const uint32_t first = part == 2 ? pm->patInterior : 0u;
-  const uint32_t count = part == 1 ? pm->patInterior : part == 2 ? nBlocks - pm->patInterior : nBlocks;
+  const uint32_t first = part == 2 ? interior : 0u;
+  const uint32_t count = part == 1 ? interior : part == 2 ? nBlocks - interior : nBlocks;
   const uint32_t pper  = g_scs_xcd ? (count + 7) / 8 : 0;
   const dim3 pgrid(g_scs_xcd ? pper * 8 : count), block(256);
   const uint32_t* hdrs   = masked ? pm->mHdrs : pm->tileHdrs;
@@ -143,7 +145,7 @@ static void launch_pat(const sb_matrix* pm, bool skipPad, bool masked, const dou
       else PAT_PICK(CP, false, false, MA);      \
     }                                           \
   } while (0)
-  if (pm->patCPT == 8) {
+  if ((masked ? pm->mCPT : pm->patCPT) == 8) {
     if (masked) PAT_PICK2(8, true);
     else PAT_PICK2(8, false);
   } else {

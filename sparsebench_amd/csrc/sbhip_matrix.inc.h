@@ -62,6 +62,15 @@ __global__ void remap_cols_k(uint32_t n, uint32_t nr, const uint32_t* __restrict
   }
 }
 
+__global__ void remap_halo_k(uint32_t n, uint32_t nr, const uint32_t* __restrict__ virt, uint32_t* colInd)
+{ // halo column nr + h -> nr + virt[h]
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t c = colInd[i];
+    if (c >= nr) colInd[i] = nr + virt[c - nr];
+  }
+}
+
 // Build the compressed mirror of an uploaded SCS C=64 matrix (pack.hip.h).  hostVal is
 // the host copy of val (dictionary detection happens on the host, with early exit).
 static void build_packed(sb_matrix* m, const double* hostVal, const uint32_t* oldToNewPerm)
@@ -162,7 +171,8 @@ struct TileWindows {
 };
 static TileWindows compute_tile_windows(const sb_matrix* m, uint32_t cpt, const uint32_t* chunkPtr,
     const uint32_t* chunkLens, const uint32_t* colInd, const double* val, const uint32_t* oldToNewPerm,
-    bool original = false) // original: windows in the ORIGINAL column numbering (level 6 of permuted matrices)
+    bool original = false, // original: windows in the ORIGINAL column numbering (level 6 of permuted matrices) ...
+    const uint32_t* haloVirt = nullptr) // ... with halo column nr + h standing at nr + haloVirt[h]
 {
   const uint32_t WMAX = 6144, MERGE_GAP = 8; // window <= 48 KiB of LDS per workgroup
   const uint32_t nTiles = (m->nChunks + cpt - 1) / cpt;
@@ -183,6 +193,7 @@ static TileWindows compute_tile_windows(const sb_matrix* m, uint32_t cpt, const 
         memcpy(&bits, val + cp + e, 8);
         if (col == 0 && bits == 0) continue; // padding (or an explicit 0.0 at column 0): slot 0
         if (!original && m->permuted && col < m->nr) col = oldToNewPerm[col];
+        if (haloVirt && col >= m->nr) col = m->nr + haloVirt[col - m->nr];
         cols.push_back(col);
         lo = std::min(lo, col), hi = std::max(hi, col);
       }
@@ -333,7 +344,16 @@ static bool pattern_classes(sb_matrix* m, PatternPlan& P)
   sb_d2h(keys.data(), dKeys, keys.size() * sizeof(uint32_t));
   sb_free(dCount), sb_free(dKeys);
   for (uint32_t t = 0; t < nTiles; t++)
-    if (count[t] > PAT_MAX) return false;
+    if (count[t] > PAT_MAX) {
+      if (getenv("SB_PACK_REPORT"))
+        fprintf(stderr, "sbhip pack: tiles of %u chunks: tile %u holds more than %u (value, slot delta) pairs\n", P.cpt, t, PAT_MAX);
+      if (getenv("SB_PACK_DEBUG")) {
+        fprintf(stderr, "  mapped %d; segments of tile %u:", (int)P.mapped, t);
+        for (uint32_t q = P.segPtr[t]; q < P.segPtr[t + 1]; q++) fprintf(stderr, " [col %u len %u slot %u]", P.segs[q].col, P.segs[q].len, P.segs[q].lds);
+        fprintf(stderr, "\n");
+      }
+      return false;
+    }
   // tiles -> classes: a class that already holds the tile's pairs, else the first class the
   // pairs still fit into, else a new class
   P.tileClass.assign(nTiles, 0);
@@ -355,7 +375,10 @@ static bool pattern_classes(sb_matrix* m, PatternPlan& P)
       if (merged.size() <= PAT_MAX) classes[c] = merged, found = (int)c;
     }
     if (found < 0) {
-      if (classes.size() >= maxClasses) return false; // no repeating patterns: not worth the tables
+      if (classes.size() >= maxClasses) { // no repeating patterns: not worth the tables
+        if (getenv("SB_PACK_REPORT")) fprintf(stderr, "sbhip pack: tiles of %u chunks: more than %zu pattern classes\n", P.cpt, maxClasses);
+        return false;
+      }
       classes.emplace_back(k, k + count[t]);
       found = (int)classes.size() - 1;
     }
@@ -474,7 +497,7 @@ static void pattern_rows(sb_matrix* m, PatternPlan& P, const std::vector<uint32_
 // not have to wait for the halo exchange (loop_body).  4-chunk tiles: one TileHdr (48 words); 8-chunk tiles: two
 // TileHdr halves interleaved word by word into 128 words (X: the tile-level fields + chunks 0-3, Y: the per-chunk
 // fields of chunks 4-7), which the kernel fetches as one 8-byte vector load.  Returns the number of segments.
-static size_t pattern_headers(sb_matrix* m, const PatternPlan& P, uint32_t** out)
+static size_t pattern_headers(sb_matrix* m, const PatternPlan& P, uint32_t** out, uint32_t* interiorOut)
 {
   const uint32_t nTiles = P.nTiles, cpt = P.cpt, LONG = cpt == 8 ? 4u : 3u;
   const std::vector<uint32_t>& segPtr = P.segPtr;
@@ -518,7 +541,7 @@ static size_t pattern_headers(sb_matrix* m, const PatternPlan& P, uint32_t** out
       memcpy(&h.seg[0][0], P.blockBase.data() + (size_t)t * 18, 18 * sizeof(uint32_t));
     }
   }
-  m->patInterior = nTiles;
+  *interiorOut = nTiles;
   if (m->nc > m->nr) {
     auto touches_halo = [&](const TileHdr& h) {
       for (uint32_t s2 = 0; s2 < h.nseg; s2++) {
@@ -530,7 +553,7 @@ static size_t pattern_headers(sb_matrix* m, const PatternPlan& P, uint32_t** out
     for (Pair& h : hdrs)
       if (touches_halo(h.x)) h.x.flags |= PAT_TOUCHES_HALO;
     auto mid = std::stable_partition(hdrs.begin(), hdrs.end(), [&](const Pair& h) { return !(h.x.flags & PAT_TOUCHES_HALO); });
-    m->patInterior = (uint32_t)(mid - hdrs.begin());
+    *interiorOut = (uint32_t)(mid - hdrs.begin());
   }
   const uint32_t stride = cpt == 8 ? 128u : 48u;
   std::vector<uint32_t> words((size_t)nTiles * stride + 128, 0u);
@@ -548,7 +571,7 @@ static size_t pattern_headers(sb_matrix* m, const PatternPlan& P, uint32_t** out
     for (const Pair& h : hdrs) nSimple += h.x.flags & PAT_SIMPLE_WINDOW;
     fprintf(stderr, "sbhip pack: %u tiles of %u chunks (%u interior, %zu simple windows, max %u entries), %zu classes, %u/%u U chunks, "
                     "%zu row patterns (%zu entries), %llu exception entries (max %u per tile), %llu code words\n",
-        nTiles, cpt, m->patInterior, nSimple, m->patWindow, P.classes.size(), m->nUniformChunks, m->nChunks, P.nRowPats,
+        nTiles, cpt, *interiorOut, nSimple, m->patWindow, P.classes.size(), m->nUniformChunks, m->nChunks, P.nRowPats,
         P.rowPats.size(), (unsigned long long)P.excEntries, P.excLds, (unsigned long long)P.words);
   }
   return nSegs;
@@ -716,7 +739,8 @@ static bool build_masked(sb_matrix* m, const PatternPlan& P)
   m->nMaskedChunks = nMasked;
   m->mDict         = Q.anyL ? 256u : 0u;
   m->mClassDict    = P.dClassDict; // (shared with the level-5 form unless the windows are the mapped ones)
-  const size_t nSegs = pattern_headers(m, Q, &m->mHdrs);
+  const size_t nSegs = pattern_headers(m, Q, &m->mHdrs, &m->mInterior);
+  m->mCPT = P.cpt, m->mNTiles = P.nTiles;
   m->mBytes = (double)Q.words * 4.0 + 2.0 * 64.0 * m->nChunks + (P.mapped ? 2.0 * P.mapStride * P.nTiles : 16.0 * nSegs) +
               (double)(P.cpt == 8 ? 384 : 192) * P.nTiles + (Q.anyL ? 4096.0 * P.classes.size() : 0.0) + 192.0 * progs.size();
   return true;
@@ -727,25 +751,45 @@ static bool build_masked(sb_matrix* m, const PatternPlan& P)
 // program.  The window is therefore laid out in ORIGINAL column order -- there a row and its neighbours keep
 // their distances whatever the sort did -- and staged through a 16-bit map, slot -> device column (relative to
 // a base per 256 slots), instead of segment by segment.
-static void build_masked_mapped(sb_matrix* m, uint32_t cpt, const uint32_t* chunkPtr, const uint32_t* chunkLens,
+static bool build_masked_mapped(sb_matrix* m, uint32_t cpt, const uint32_t* chunkPtr, const uint32_t* chunkLens,
     const uint32_t* colInd, const double* val)
 {
   const char* env = getenv("SB_PACK");
-  if ((env ? atoi(env) : 6) < 6 || m->nChunks == 0) return;
-  TileWindows W = compute_tile_windows(m, cpt, chunkPtr, chunkLens, colInd, val, nullptr, true);
-  if (!W.ok) return;
+  if ((env ? atoi(env) : 6) < 6 || m->nChunks == 0) return false;
+  // Halo columns (>= nr) are numbered by the partitioner in the order it met them (src/comm.c:60-110: first seen inside
+  // an owner's group): next to a rank boundary that interleaves the neighbour's first grid lines, and one tile with > 255
+  // (value, slot delta) pairs costs the whole matrix its pattern levels.  The window is private: where the host has
+  // passed the halo columns' global ids (sb_set_external_ids, from commPartition), they stand in it in ascending global
+  // order -- for a stencil the neighbour's plane, line by line, like the rank's own planes.
+  const uint32_t nExt = m->nc - m->nr;
+  std::vector<uint32_t> haloVirt, haloReal;
+  if (nExt && g_externalIds.size() == nExt) {
+    haloReal.resize(nExt), haloVirt.resize(nExt);
+    for (uint32_t h = 0; h < nExt; h++) haloReal[h] = h;
+    std::stable_sort(haloReal.begin(), haloReal.end(), [&](uint32_t a2, uint32_t b2) { return g_externalIds[a2] < g_externalIds[b2]; });
+    for (uint32_t v = 0; v < nExt; v++) haloVirt[haloReal[v]] = v;
+  }
+  const bool virt = !haloVirt.empty();
+  TileWindows W = compute_tile_windows(m, cpt, chunkPtr, chunkLens, colInd, val, nullptr, true, virt ? haloVirt.data() : nullptr);
+  if (!W.ok) return false;
   PatternPlan P;
   P.cpt = cpt, P.nTiles = (m->nChunks + cpt - 1) / cpt, P.mapped = true;
   // slot -> device column; a block of 256 slots must span < 65536 device columns: where it would not, the
   // segment that starts inside the block is moved up to the next block boundary
-  std::vector<uint32_t> o2n(m->nr);
-  sb_d2h(o2n.data(), m->oldToNew, o2n.size() * sizeof(uint32_t));
-  auto dev_col = [&](uint32_t orig) { return orig < m->nr ? o2n[orig] : orig; };
+  std::vector<uint32_t> o2n;
+  if (m->permuted) {
+    o2n.resize(m->nr);
+    sb_d2h(o2n.data(), m->oldToNew, o2n.size() * sizeof(uint32_t));
+  }
+  auto dev_col = [&](uint32_t orig) { // window (original / virtual halo) numbering -> device column
+    if (orig >= m->nr) return virt ? m->nr + haloReal[orig - m->nr] : orig;
+    return m->permuted ? o2n[orig] : orig;
+  };
   uint32_t maxWin = 1;
   for (int pass = 0; pass < 2; pass++) {
     if (pass == 1) {
       P.mapStride = ((maxWin + 255u) / 256u) * 256u;
-      if (P.mapStride > (cpt == 8 ? 15u : 12u) * 256u) return; // what a workgroup stages in one pass (spmv_scs64_pat: WB); block bases: <= 18 header words
+      if (P.mapStride > (cpt == 8 ? 15u : 12u) * 256u) return false; // what a workgroup stages in one pass (spmv_scs64_pat: WB); block bases: <= 18 header words
       P.slotMap.assign((size_t)P.nTiles * P.mapStride, 0), P.blockBase.assign((size_t)P.nTiles * 18, 0);
     }
     for (uint32_t t = 0; t < P.nTiles; t++) {
@@ -764,11 +808,11 @@ static void build_masked_mapped(sb_matrix* m, uint32_t cpt, const uint32_t* chun
               fits = h - l < 65536u;
             }
             if (fits) { sg.lds = win, win = w, blk = b, lo = l, hi = h; break; }
-            if (tries == 1) return; // a single segment whose device columns are too far apart
+            if (tries == 1) return false; // a single segment whose device columns are too far apart
             win = (win + 255u) / 256u * 256u; // start the segment on a block boundary
           }
         }
-        if (win > 6144u) return;
+        if (win > 6144u) return false;
         maxWin = std::max(maxWin, win);
       } else {
         uint16_t* mp  = P.slotMap.data() + (size_t)t * P.mapStride;
@@ -791,7 +835,13 @@ static void build_masked_mapped(sb_matrix* m, uint32_t cpt, const uint32_t* chun
   uint32_t *origCol = nullptr, *slots = nullptr;
   HIP_CHECK(hipMalloc(&origCol, ((size_t)m->nElems + SCS_SLACK) * sizeof(uint32_t)));
   sb_d2d(origCol, m->colInd, ((size_t)m->nElems + SCS_SLACK) * sizeof(uint32_t)); // (on g.stream, like the kernels below)
-  hipLaunchKernelGGL(remap_cols_k, dim3(stream_grid(m->nElems, 256)), dim3(256), 0, g.stream, m->nElems, m->nr, m->newToOld, origCol);
+  if (m->permuted)
+    hipLaunchKernelGGL(remap_cols_k, dim3(stream_grid(m->nElems, 256)), dim3(256), 0, g.stream, m->nElems, m->nr, m->newToOld, origCol);
+  uint32_t* dVirt = nullptr;
+  if (virt) {
+    dVirt = (uint32_t*)upload(haloVirt.data(), haloVirt.size() * sizeof(uint32_t));
+    hipLaunchKernelGGL(remap_halo_k, dim3(stream_grid(m->nElems, 256)), dim3(256), 0, g.stream, m->nElems, m->nr, dVirt, origCol);
+  }
   uint32_t* dSegPtr = (uint32_t*)upload(P.segPtr.data(), P.segPtr.size() * sizeof(uint32_t));
   TileSeg* dSegs    = (TileSeg*)upload(P.segs.data(), P.segs.size() * sizeof(TileSeg));
   std::vector<PackMeta> meta(m->nChunks);
@@ -799,10 +849,10 @@ static void build_masked_mapped(sb_matrix* m, uint32_t cpt, const uint32_t* chun
   const uint64_t groups = (uint64_t)meta.back().grp + ((meta.back().info & 0x7FFFFFFFu) + 3u) / 4u;
   HIP_CHECK(hipMalloc(&slots, (size_t)groups * 512 + 1024));
   hipLaunchKernelGGL(pack_slots_k, dim3((m->nChunks + 3) / 4), dim3(256), 0, g.stream, m->chunkPtr, m->chunkLens, origCol,
-      m->val, m->pmeta, dSegPtr, dSegs, m->nChunks, 0u /* padding: original column 0 */, slots, cpt);
+      m->val, m->pmeta, dSegPtr, dSegs, m->nChunks, m->permuted ? 0u : m->padCol /* padding: original column 0 */, slots, cpt);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(g.stream));
-  sb_free(origCol), sb_free(dSegPtr);
+  sb_free(origCol), sb_free(dSegPtr), sb_free(dVirt);
   P.slots = slots;
   bool kept = false;
   if (pattern_classes(m, P)) {
@@ -813,21 +863,21 @@ static void build_masked_mapped(sb_matrix* m, uint32_t cpt, const uint32_t* chun
   P.free_temporaries();
   if (!kept) {
     P.free_tables(), sb_free(dSegs);
-    return;
+    return false;
   }
   m->mOwnsTables = true, m->mSegs = dSegs, m->mWindow = maxWin, m->mMapStride = P.mapStride;
   m->mSlotMap = (uint16_t*)upload(P.slotMap.data(), P.slotMap.size() * sizeof(uint16_t));
   sb_free(P.dRowBase), sb_free(P.dTileClass); // (mClassDict stays)
+  return true;
 }
 
-// Chunks per tile of the pattern kernel: 8 (two chunks per wave: one header fetch, window staging and barrier for
-// twice the rows) where every 8-chunk window fits LDS, else 4.  SB_PAT_CPT=4 keeps level 3's tiles.
-static void build_patterns(sb_matrix* m, const uint32_t* chunkPtr, const uint32_t* chunkLens, const uint32_t* colInd,
+// Levels 4-5 on windows in the device numbering.  Chunks per tile: 8 (two chunks per wave: one header fetch, window
+// staging and barrier for twice the rows) where every 8-chunk window fits and no tile has more pairs than a class holds,
+// else 4.  SB_PAT_CPT=4 keeps level 3's tiles.  true: built; level 6 on the same windows has been tried (m->mHdrs).
+static bool build_level5(sb_matrix* m, const uint32_t* chunkPtr, const uint32_t* chunkLens, const uint32_t* colInd,
     const double* val, const uint32_t* oldToNewPerm, uint32_t forceCpt = 0)
 {
-  if (m->usePacked != 2 || m->nDict <= 0) return;
   const char* env = getenv("SB_PACK");
-  if ((env ? atoi(env) : 4) < 4) return;
   PatternPlan P;
   uint32_t* slots8 = nullptr; // device: window slots for 8-chunk tiles (temporary)
   {
@@ -837,6 +887,7 @@ static void build_patterns(sb_matrix* m, const uint32_t* chunkPtr, const uint32_
   }
   if (P.cpt == 8) {
     TileWindows W = compute_tile_windows(m, 8, chunkPtr, chunkLens, colInd, val, oldToNewPerm);
+    if (!W.ok && getenv("SB_PACK_REPORT")) fprintf(stderr, "sbhip pack: tiles of 8 chunks: a window does not fit\n");
     if (!W.ok) P.cpt = 4;
     else {
       P.segPtr = std::move(W.segPtr), P.segs = std::move(W.segs);
@@ -866,7 +917,7 @@ static void build_patterns(sb_matrix* m, const uint32_t* chunkPtr, const uint32_
   m->patCPT   = P.cpt;
   P.nTiles    = (m->nChunks + P.cpt - 1) / P.cpt;
   m->patNTiles = P.nTiles;
-  auto give_up = [&]() { // the matrix stays at level 3
+  auto give_up = [&]() { // no levels 4-5
     sb_free(slots8);
     if (m->patSegs != m->tileSegs) sb_free(m->patSegs);
     m->patSegs = nullptr;
@@ -874,14 +925,13 @@ static void build_patterns(sb_matrix* m, const uint32_t* chunkPtr, const uint32_
   };
   if (!pattern_classes(m, P)) { // (more pairs than a class holds in some tile: try the smaller tiles before giving up)
     give_up();
-    if (P.cpt == 8) build_patterns(m, chunkPtr, chunkLens, colInd, val, oldToNewPerm, 4);
-    return;
+    return P.cpt == 8 ? build_level5(m, chunkPtr, chunkLens, colInd, val, oldToNewPerm, 4) : false;
   }
   pattern_codes(m, P);
   pattern_rows(m, P, P.dom, (env ? atoi(env) : 5) >= 5);
   if (P.words > 0xFFFFFFFFull || P.excEntries > 0xFFFFFFFFull) { // positions are 32-bit
     give_up();
-    return;
+    return false;
   }
   m->rowBase = P.dRowBase, m->tileClass = P.dTileClass, m->classDict = P.dClassDict;
   // final form: L code words / expanded exception rows of the U chunks
@@ -899,27 +949,50 @@ static void build_patterns(sb_matrix* m, const uint32_t* chunkPtr, const uint32_
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(g.stream));
   sb_free(dOff), sb_free(dFlags), sb_free(slots8);
-  // level 6 on the same windows; with a row permutation, on windows in original column order
-  if (build_masked(m, P)) m->mSegs = m->patSegs, m->mWindow = m->patWindow;
-  else if (m->permuted) {
-    P.free_temporaries();
-    build_masked_mapped(m, P.cpt, chunkPtr, chunkLens, colInd, val);
-  }
+  // level 6 on the same windows (the tile shape of choice only: build_patterns tries its own shapes otherwise)
+  if (P.cpt == 8 || m->nChunks <= 4)
+    if (build_masked(m, P)) m->mSegs = m->patSegs, m->mWindow = m->patWindow;
   P.free_temporaries();
   m->rowPats     = (PatEntry*)upload(P.rowPats.data(), P.rowPats.size() * sizeof(PatEntry));
   m->nRowPats    = (uint32_t)P.nRowPats;
   m->nPatClasses = (uint32_t)P.classes.size();
   m->patDict     = P.anyL ? 256u : 0u;
   m->patExcLds   = P.excLds;
-  const size_t nSegs = pattern_headers(m, P, &m->tileHdrs);
+  const size_t nSegs = pattern_headers(m, P, &m->tileHdrs, &m->patInterior);
   m->patBytes = (double)P.words * 4.0 + 16.0 * (double)P.excEntries + 2.0 * 64.0 * m->nChunks + 16.0 * nSegs +
                 (double)(P.cpt == 8 ? 384 : 192) * P.nTiles + (P.anyL ? 4096.0 * P.classes.size() : 0.0) + 16.0 * P.rowPats.size();
+  return true;
+}
+
+// Levels 4-6.  Level 6 does not depend on level 5: with windows in original column order (build_masked_mapped) a tile
+// has few (value, slot delta) pairs whatever the sigma sort and the halo numbering did to the device columns -- a
+// rank-local brick with a lower neighbour has > 255 pairs per tile in the device numbering (no levels 4-5 at all: its
+// halo columns are not permuted, its own are) and 19 programs in the original one.
+static void build_patterns(sb_matrix* m, const uint32_t* chunkPtr, const uint32_t* chunkLens, const uint32_t* colInd,
+    const double* val, const uint32_t* oldToNewPerm)
+{
+  if (m->usePacked != 2 || m->nDict <= 0) return;
+  const char* env = getenv("SB_PACK");
+  if ((env ? atoi(env) : 4) < 4) return;
+  const bool level5 = build_level5(m, chunkPtr, chunkLens, colInd, val, oldToNewPerm);
+  if (!m->mHdrs && (m->permuted || !level5 || m->patCPT != 8)) {
+    const char* ec = getenv("SB_PAT_CPT");
+    const bool eight = !(ec && atoi(ec) == 4) && m->nChunks > 4;
+    if (!(eight && build_masked_mapped(m, 8, chunkPtr, chunkLens, colInd, val)))
+      build_masked_mapped(m, 4, chunkPtr, chunkLens, colInd, val);
+  }
   // Default kernel: the masked row programs wherever they were built (round 2, stand-alone launches: 64^3 5.6 us against
   // 6.4 us for level 3 and 7.7 us for level 5; 96^3 10.0 / 18.5 / 15.8; 128^3 18.6 / - / 27.5).  Otherwise the level-5
   // kernel once the matrix is more than one round of resident workgroups (8 per CU, 4 chunks each); below that
   // everything is one dependent-latency chain and the level-3 kernel's is shorter (64^3: 46.7k vs 43.2k CG it/s;
   // 96^3: 22.8k vs 26.3k).  sb_matrix_use_packed(m, 3) selects it regardless.
-  m->usePacked = m->mHdrs ? 5 : (m->nChunks + 3) / 4 > (uint32_t)g.prop.multiProcessorCount * 8u ? 3 : 2;
+  if (m->mHdrs) m->usePacked = 5;
+  else if (level5) m->usePacked = (m->nChunks + 3) / 4 > (uint32_t)g.prop.multiProcessorCount * 8u ? 3 : 2;
+}
+
+void sb_set_external_ids(const uint32_t* global_ids, uint32_t n)
+{
+  g_externalIds.assign(global_ids, global_ids + (global_ids ? n : 0));
 }
 
 sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, uint32_t nChunks,

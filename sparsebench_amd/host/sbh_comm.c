@@ -378,6 +378,7 @@ void commPartition(Comm* c, GMatrix* A)
     }
   A->nc            = A->nc + (CG_UINT)nExt; /* src/comm.c:616 */
   c->externalCount = nExt;
+  sb_set_external_ids(c->externalGlobal, (uint32_t)nExt); /* window layout hint for the upload that follows (sbhip.h) */
 
   c->sources    = (int*)malloc(((size_t)P + 1) * sizeof(int));
   c->recvCounts = (int*)malloc(((size_t)P + 1) * sizeof(int));
