@@ -768,13 +768,13 @@ struct HaloPush {
   long long timeoutTicks;             // bound of the receivers' waits (halo_pull_k, HALO SpMV)
 };
 
-__global__ __launch_bounds__(256) void halo_push_k(HaloPush hp, const double* __restrict__ x,
-    unsigned long long seq, const int* __restrict__ stop)
+// the push of one workgroup out of nBlocks (its own kernel below; or the first workgroups of the HALO SpMV)
+__device__ __forceinline__ void halo_push_block(const HaloPush& hp, const double* __restrict__ x, unsigned long long seq,
+    uint32_t block, uint32_t nBlocks)
 {
-  if (stop && *stop) return; // the same decision on every rank (the loop test is all-reduced)
   const unsigned par    = (unsigned)(seq & 1ull);
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < hp.n; i += stride) {
+  const uint32_t stride = nBlocks * blockDim.x;
+  for (uint32_t i = block * blockDim.x + threadIdx.x; i < hp.n; i += stride) {
     const uint32_t d = hp.dest[i];
     __hip_atomic_store(hp.stage[d] + (size_t)par * hp.ext[d] + hp.slot[i],
         (unsigned long long)__double_as_longlong(x[hp.packIdx[i]]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -783,13 +783,20 @@ __global__ __launch_bounds__(256) void halo_push_k(HaloPush hp, const double* __
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned prev = atomicAdd(hp.done, 1u);
-    if (prev == gridDim.x - 1u) { // every workgroup has pushed: tell the receivers
+    if (prev == nBlocks - 1u) { // every workgroup has pushed: tell the receivers
       *hp.done = 0u;
       __threadfence_system();
       for (int d = 0; d < hp.ndest; d++)
         __hip_atomic_store(hp.flag[d] + par * P2P_MAX + hp.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void halo_push_k(HaloPush hp, const double* __restrict__ x,
+    unsigned long long seq, const int* __restrict__ stop)
+{
+  if (stop && *stop) return; // the same decision on every rank (the loop test is all-reduced)
+  halo_push_block(hp, x, seq, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void halo_pull_k(const int* __restrict__ srcRank, const int* __restrict__ rdispl,

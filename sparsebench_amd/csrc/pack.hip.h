@@ -528,6 +528,11 @@ struct HaloWait {
   int* err;
   int* stopw;             // CgScalars::stop, raised together with err: no iterating on a stale halo
   long long timeoutTicks; // bound of the wait (HaloPush::timeoutTicks)
+  // the rank's own push rides in the same launch: its first nPush workgroups send x[elementsToSend] to the neighbours
+  // (kernels.hip.h: halo_push_block) instead of multiplying a tile -- they are dispatched first, the tiles that wait
+  // for the neighbours' pushes last.  nPush = 0: a separate halo_push_k has been launched.
+  const HaloPush* push; // device copy
+  uint32_t nPush;       // a multiple of 8 (keeps the workgroup -> XCD assignment of the tiles)
 };
 constexpr uint32_t PAT_EXC_LDS_MAX   = 1024; // exception entries per 4 chunks of a tile (16 KiB of LDS) at most
 
@@ -705,7 +710,13 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
   // A launch covers headers [firstHdr, firstHdr + nHdrs).  Headers are stored with the tiles
   // that touch no halo column first, so that on several ranks the interior part of the
   // product can run while the halo is still in flight (one launch for each part).
-  const uint32_t tile0 = blocksPerXcd ? xcd_block(blockIdx.x, blocksPerXcd) : blockIdx.x;
+  if (HALO && blockIdx.x < hw.nPush) { // (uniform per workgroup) this workgroup carries the rank's halo push
+    if (*stop) return;
+    halo_push_block(*hw.push, x, hw.seq, blockIdx.x, hw.nPush);
+    return;
+  }
+  const uint32_t bid   = HALO ? blockIdx.x - hw.nPush : blockIdx.x;
+  const uint32_t tile0 = blocksPerXcd ? xcd_block(bid, blocksPerXcd) : bid;
   const uint32_t hidx  = firstHdr + min(tile0, nHdrs - 1u); // clamped: every load below is unconditional
   // round trip 1: ONE vector load brings the tile header (lanes 0..47) and the stop flag
   // (lane 48); fields are then read out of the lanes (v_readlane -> SGPRs)

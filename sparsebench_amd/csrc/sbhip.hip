@@ -243,6 +243,7 @@ struct sb_halo {
   unsigned long long* stage = nullptr; // own fine-grained area: [2][externalCount] values, then [2][P2P_MAX] flags
   void* peerStage[P2P_MAX] = {};       // destinations' areas as opened here (by destination index)
   HaloPush push;                       // kernel argument of halo_push_k
+  HaloPush* dPush = nullptr;           // device copy (the HALO SpMV's push workgroups read it)
   uint32_t *slot = nullptr; uint8_t* dest = nullptr; unsigned int* done = nullptr; // device arrays behind `push`
   int *dSrcRank = nullptr, *dRdispl = nullptr, *dRcount = nullptr, *err = nullptr;
   unsigned long long seq = 0;

@@ -346,10 +346,20 @@ static void loop_body(sb_cg* s, int k)
   } else if (multi_rank() && s->halo && s->halo->p2p && spmv_can_fuse_dot(s) && spmv_uses_patterns(s->A)) {
     // :122-126 over peer-mapped memory with the pull inside the SpMV: the halo-touching tiles (stored
     // last) wait for the neighbours' pushes themselves and read the staging area; interior tiles hide it
-    halo_exchange(s->halo, s->p, stop, nullptr, true, true);
-    mark(s, R_COMM);
+    // SB_HALO_PUSH_INSIDE=1: the push rides in the SpMV launch too (its first 16 workgroups) instead of a launch of its
+    // own.  Bit-identical (tests/test_gpu_multirank.py runs both); NOT the default: the only place it can be timed here
+    // is N ranks sharing one GPU, where it is slower (2 x 128^3: 291 vs 178 us per step -- a rank's waiting tiles keep
+    // the other rank's SpMV, and with it its push, off the CUs), and on ranks with a GPU each, where it should save the
+    // ~4.5 us launch, it cannot be measured from this box.
     sb_halo* h = s->halo;
+    static const bool pushInside = getenv("SB_HALO_PUSH_INSIDE") && atoi(getenv("SB_HALO_PUSH_INSIDE")) != 0;
     HaloWait hw;
+    memset(&hw, 0, sizeof hw);
+    if (pushInside) {
+      ++h->seq;
+      hw.push = h->dPush, hw.nPush = h->totalSend ? 16u : 0u;
+    } else halo_exchange(h, s->p, stop, nullptr, true, true);
+    mark(s, R_COMM);
     hw.flags = h->stage + 2 * (size_t)h->externalCount;
     hw.ext   = reinterpret_cast<const double*>(h->stage + (h->seq & 1ull) * (size_t)h->externalCount);
     hw.src = h->dSrcRank, hw.nsrc = h->indegree, hw.seq = h->seq, hw.err = h->err;

@@ -325,7 +325,8 @@ static void halo_p2p_release(sb_halo* h)
   }
   if (h->stage) (void)hipFree(h->stage);
   sb_free(h->slot), sb_free(h->dest), sb_free(h->done), sb_free(h->dSrcRank), sb_free(h->dRdispl), sb_free(h->dRcount);
-  sb_free(h->err);
+  sb_free(h->err), sb_free(h->dPush);
+  h->dPush = nullptr;
   h->stage = nullptr, h->slot = nullptr, h->dest = nullptr, h->done = nullptr, h->dSrcRank = nullptr;
   h->dRdispl = nullptr, h->dRcount = nullptr, h->err = nullptr, h->p2p = false;
 }
@@ -468,6 +469,7 @@ static void halo_p2p_setup(sb_halo* h)
   sb_free(dflag);
   if (!on) halo_p2p_release(h);
   h->p2p = on;
+  if (on) h->dPush = (HaloPush*)upload(&h->push, sizeof h->push);
   if (on) snprintf(h->p2pReason, sizeof h->p2pReason, "on: %d destinations mapped, 6 self-test exchanges ok", h->outdegree);
   else snprintf(h->p2pReason, sizeof h->p2pReason, "off: %s", why[0] ? why : "unknown");
   if (getenv("SB_PACK_REPORT") || getenv("SB_P2P_REPORT"))

@@ -121,7 +121,7 @@ static void launch_pat(const sb_matrix* pm, bool skipPad, bool masked, const dou
   const uint32_t first = part == 2 ? interior : 0u;
   const uint32_t count = part == 1 ? interior : part == 2 ? nBlocks - interior : nBlocks;
   const uint32_t pper  = g_scs_xcd ? (count + 7) / 8 : 0;
-  const dim3 pgrid(g_scs_xcd ? pper * 8 : count), block(256);
+  const dim3 pgrid((g_scs_xcd ? pper * 8 : count) + (halo ? hw.nPush : 0u)), block(256);
   const uint32_t* hdrs   = masked ? pm->mHdrs : pm->tileHdrs;
   const uint32_t* codes  = masked ? pm->mStream : pm->jcodes;
   const uint16_t* rbase  = masked ? reinterpret_cast<const uint16_t*>(pm->mRowBase) : pm->rowBase;

@@ -72,6 +72,10 @@ def main():
         assert (np.abs(rr - ref) / ref)[live].max() <= 1e-12  # north_star tolerance vs the MPI reference
     dist.barrier()
     print("VPHASE_RUNS %d" % vphase_seen, flush=True)
+    mch = C.c_uint32(0)
+    L.sb_matrix_row_programs(prob.matrix, C.byref(mch))
+    nchunks = (prob.nr + 63) // 64
+    print("ROW_PROGRAMS rank %d %d of %d" % (rank, mch.value, nchunks if fmt == "scs" and Cc == 64 else 0), flush=True)
     # the data plane every rank REALLY used (both set-ups are collective decisions: all ranks agree)
     p2p, halo_p2p = L.sb_comm_p2p_enabled(), L.sb_halo_p2p_enabled(prob.halo)
     flags = torch.tensor([p2p, halo_p2p], dtype=torch.int32)

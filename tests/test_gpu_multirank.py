@@ -5,6 +5,7 @@ pack indices through the SCS permutation, halo columns in the compressed stream 
 windows, received entries landing in the tail of p, the split local-reduce / all-reduce /
 scalar-step sequence, and the device-side loop exit on every rank."""
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -31,7 +32,7 @@ def _free_port():
     ("scs", 64, 1, 48, 3, 150),     # several tiles per rank, many exchanges: staging-area parity, flags, row patterns
     ("scs", 64, 256, 128, 2, 20),   # BASELINE configs[3]'s brick (128^3 per rank, Sell-64-256), two ranks on the one GPU
 ])
-@pytest.mark.parametrize("p2p", ["1", "0"])
+@pytest.mark.parametrize("p2p", ["1", "0", "push-inside"])
 def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax, p2p):
     """p2p=1: the dot all-reduces happen inside the scalar step over peer-mapped (IPC) memory when the
     ranks' kernels really run concurrently on the one GPU (otherwise the self-test falls back, which the
@@ -40,8 +41,14 @@ def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax, p2p):
     # p2p=0: transport send-recv, and the two-stream halo overlap (off by default) rides along to keep it covered
     # SB_VPHASE_MAXGRID: the one-launch vector phase (in-kernel all-reduce only) waits for all of its own workgroups;
     # with `size` ranks on ONE GPU their grids must be resident together, so each is capped
+    # "push-inside": p2p = 1 with the halo push carried by the first workgroups of the SpMV launch (SB_HALO_PUSH_INSIDE=1)
+    inside = p2p == "push-inside"
+    if inside:
+        p2p = "1"
+        if (fmt, n) not in (("scs", 16), ("scs", 48)) or Cc != 64:
+            pytest.skip("the push-inside variant is covered by the Sell-64 cases with 16^3 and 48^3 per rank")
     env = dict(os.environ, OMP_NUM_THREADS="1", SB_P2P=p2p, SB_P2P_REPORT="1", SB_HALO_OVERLAP="1" if p2p == "0" else "0",
-               SB_VPHASE_MAXGRID="64")
+               SB_VPHASE_MAXGRID="64", SB_HALO_PUSH_INSIDE="1" if inside else "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(size),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "gpu_multirank_worker.py"), fmt, str(Cc), str(sigma), str(n), str(itermax)]
@@ -49,6 +56,12 @@ def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax, p2p):
     text = out.stdout.decode()
     assert out.returncode == 0, text[-4000:]
     assert "GPU_MULTIRANK_OK %s %d %d %d %d" % (fmt, Cc, sigma, n, size) in text, text[-3000:]
+    if (fmt, Cc, n) == ("scs", 64, 128):
+        # BASELINE configs[3]'s brick: EVERY rank's matrix -- also the one whose halo plane lies below its first rows --
+        # gets the default pattern kernel (level 6) for all of its chunks (halo columns in ascending global order inside
+        # the private windows: sb_set_external_ids from commPartition)
+        progs = re.findall(r"ROW_PROGRAMS rank (\d+) (\d+) of (\d+)", text)
+        assert len(progs) == size and all(int(a) == int(b) > 0 for _, a, b in progs), progs
     why = [ln for ln in text.splitlines() if ln.startswith(("P2P_REASON", "HALO_P2P_REASON"))]
     if p2p == "0":
         assert "P2P_ENABLED 0" in text and "HALO_P2P_ENABLED 0" in text
