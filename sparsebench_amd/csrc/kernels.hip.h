@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void cg_x_finalize(uint32_t n, double* x, cons
 // OP 0: dot(a, b)                                       (ddot, src/solver.c:41-62)
 // OP 1: x += alpha p ; r -= alpha Ap ; dot(r, r)        (src/CGSolver.c:127-128 + :112)
 // OP 2: r = b - Ap ; dot(r, r)                          (src/CGSolver.c:97-98)
-// OP 3: r -= alpha Ap ; dot(r, r)                       (x is updated by the next cg_update_p)
+// (the fused loop's r update is cg_update_r_k below)
 template <int OP>
 __global__ __launch_bounds__(256) void dot_spans_k(uint32_t n, const double* a, const double* b,
     double* x, double* r, const CgScalars* __restrict__ S, double* __restrict__ partials,
@@ -493,39 +493,10 @@ __global__ __launch_bounds__(256) void dot_spans_k(uint32_t n, const double* a, 
   const uint32_t lane   = threadIdx.x & 63u;
   const uint32_t nSpans = ((n + 255u) >> 8) * 2u; // whole 256-groups
   const uint32_t nWaves = gridDim.x * (blockDim.x >> 6);
-  uint32_t s            = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  // OP 3 (once per CG iteration): two spans per step while both lie fully inside n, and the
-  // first pair's loads go in flight together with the stop flag / alpha instead of behind them
-  const bool pair0 = OP == 3 && s + nWaves < nSpans && (s + nWaves) * 128u + 128u <= n; // wave-uniform
-  double2 r0 = { 0.0, 0.0 }, a0 = r0, r1 = r0, a1 = r0;
-  if (pair0) {
-    const uint32_t e0 = s * 128u + lane * 2u, e1 = (s + nWaves) * 128u + lane * 2u;
-    r0 = *reinterpret_cast<const double2*>(r + e0), a0 = *reinterpret_cast<const double2*>(b + e0);
-    r1 = *reinterpret_cast<const double2*>(r + e1), a1 = *reinterpret_cast<const double2*>(b + e1);
-  }
   if (stop && *stop) return;
   double alpha = 0.0, nalpha = 0.0;
-  if (OP == 1 || OP == 3) alpha = S->alpha, nalpha = -alpha;
-  if (OP == 3) {
-    bool have = pair0;
-    while (have) {
-      const uint32_t e0 = s * 128u + lane * 2u, e1 = (s + nWaves) * 128u + lane * 2u;
-      r0.x = r0.x + nalpha * a0.x, r0.y = r0.y + nalpha * a0.y;
-      r1.x = r1.x + nalpha * a1.x, r1.y = r1.y + nalpha * a1.y;
-      *reinterpret_cast<double2*>(r + e0) = r0;
-      *reinterpret_cast<double2*>(r + e1) = r1;
-      const double t0 = butterfly32(r0.x * r0.x + r0.y * r0.y), t1 = butterfly32(r1.x * r1.x + r1.y * r1.y);
-      if ((lane & 31u) == 0) partials[s * 2u + (lane >> 5)] = t0, partials[(s + nWaves) * 2u + (lane >> 5)] = t1;
-      s += 2u * nWaves;
-      have = s + nWaves < nSpans && (s + nWaves) * 128u + 128u <= n;
-      if (have) {
-        const uint32_t f0 = s * 128u + lane * 2u, f1 = (s + nWaves) * 128u + lane * 2u;
-        r0 = *reinterpret_cast<const double2*>(r + f0), a0 = *reinterpret_cast<const double2*>(b + f0);
-        r1 = *reinterpret_cast<const double2*>(r + f1), a1 = *reinterpret_cast<const double2*>(b + f1);
-      }
-    }
-  }
-  for (; s < nSpans; s += nWaves) { // (OP 3: what the paired loop left over)
+  if (OP == 1) alpha = S->alpha, nalpha = -alpha;
+  for (uint32_t s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < nSpans; s += nWaves) {
     const uint32_t e = s * 128u + lane * 2u;
     double t         = 0.0;
     if (OP == 0) {
@@ -555,19 +526,6 @@ __global__ __launch_bounds__(256) void dot_spans_k(uint32_t n, const double* a, 
         r[e]            = rn;
         t               = rn * rn + 0.0;
       }
-    } else if (OP == 3) { // b = Ap
-      if (e + 1 < n) {
-        double2 rv       = *reinterpret_cast<double2*>(r + e);
-        const double2 av = *reinterpret_cast<const double2*>(b + e);
-        rv.x = rv.x + nalpha * av.x;
-        rv.y = rv.y + nalpha * av.y;
-        *reinterpret_cast<double2*>(r + e) = rv;
-        t = rv.x * rv.x + rv.y * rv.y;
-      } else if (e < n) {
-        const double rn = r[e] + nalpha * b[e];
-        r[e]            = rn;
-        t               = rn * rn + 0.0;
-      }
     } else { // a = b (rhs), b = Ap
       if (e + 1 < n) {
         const double2 bv = *reinterpret_cast<const double2*>(a + e);
@@ -592,7 +550,7 @@ __global__ __launch_bounds__(256) void dot_spans_k(uint32_t n, const double* a, 
 // 256-groups (two adjacent spans), so it forms the group's LEVEL-1 value ((q0 + q1) + q2) + q3 in registers and the
 // scalar step that follows reads n/256 doubles instead of n/64 (reduce_final_1024, l1).  The first group's loads go
 // in flight together with the stop flag / alpha instead of behind them.  Same arithmetic, same order, same bits as
-// dot_spans_k<3> + level1().
+// a per-span r update followed by level1().
 __global__ __launch_bounds__(256) void cg_update_r_k(uint32_t n, const double* __restrict__ Ap, double* r,
     const CgScalars* __restrict__ S, double* __restrict__ l1out, const int* __restrict__ stop)
 {
@@ -1127,7 +1085,7 @@ __device__ __forceinline__ bool lead_step(CgScalars* S, const double* __restrict
 }
 
 // alpha step + r -= alpha Ap + level-0 partials of r.r   (src/CGSolver.c:124-126, :128, :112)
-// = cg_scalar_k<2> followed by dot_spans_k<3>, element for element
+// = cg_scalar_k<2> followed by the r update (cg_update_r_k's arithmetic, level-0 partials), element for element
 __global__ __launch_bounds__(1024) void cg_lead_r_k(uint32_t n, const double* __restrict__ Ap, double* r, CgScalars* S,
     const double* __restrict__ pApPartials, double* __restrict__ rrPartials, uint32_t m, double* __restrict__ rr_hist,
     double* __restrict__ pAp_hist, Lead* Ld, long long timeoutTicks)

@@ -232,7 +232,7 @@ static void launch_dot_spans(int op, uint32_t n, const double* a, const double* 
   if (op == 0) hipLaunchKernelGGL((dot_spans_k<0>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
   else if (op == 1) hipLaunchKernelGGL((dot_spans_k<1>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
   else if (op == 2) hipLaunchKernelGGL((dot_spans_k<2>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
-  else hipLaunchKernelGGL((dot_spans_k<3>), grid, block, 0, g.stream, n, a, b, x, r, S, partials, stop);
+  else SB_FATAL("launch_dot_spans: unknown op %d", op);
   HIP_CHECK(hipGetLastError());
 }
 
