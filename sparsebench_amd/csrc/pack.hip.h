@@ -632,7 +632,9 @@ typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));
 typedef unsigned long long u64x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
-// acc += prod in the lanes of `mask` only
+// acc += prod in the lanes of `mask` only.  EXEC is set for the one add and put back to all ones: the caller is in
+// wave-uniform control flow with all 64 lanes active (spmv_scs64_pat: full waves of a 256-thread workgroup, every
+// branch around the accumulate loop is on scalar values), which the compiler does not know and need not.
 __device__ __forceinline__ void masked_add(double& acc, double prod, unsigned long long mask)
 {
   asm volatile("s_mov_b64 exec, %2\n\tv_add_f64 %0, %0, %1\n\ts_mov_b64 exec, -1" : "+v"(acc) : "v"(prod), "s"(mask));
