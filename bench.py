@@ -424,6 +424,13 @@ def run_rank(args):
         default = prob.use_packed(args.pack_mode) if args.pack_mode >= 0 else prob.pack_info()["mode"]
         modes = [default] + ([0] if default != 0 else [])
         res = measure(prob, modes)
+        rank_modes = [default]
+        if dist is not None:  # which SpMV kernel every rank ran (rank-local matrices differ: halo above / below / both)
+            import torch
+            mine = torch.tensor([default], dtype=torch.int32)
+            got = [torch.zeros(1, dtype=torch.int32) for _ in range(world)]
+            dist.all_gather(got, mine)
+            rank_modes = [int(t[0]) for t in got]
         if rank == 0:
             d = res[default]
             it_s = K / d["t_clean"]
@@ -452,7 +459,7 @@ def run_rank(args):
                            "dot_allreduce_reason": (L.sb_comm_p2p_reason().decode() if world > 1 else None),
                            "halo_exchange_reason": (L.sb_halo_p2p_reason(prob.halo).decode() if world > 1 else None),
                            "spmv_x_staging": ("lds_window" if default >= 2 else "l1_l2_gather (LDS staging measured neutral at 12 B/element)"),
-                           "fused_dots": True, "vector_phase_one_launch": bool(vphase), "launches_per_iteration": launches,
+                           "fused_dots": True, "vector_phase_one_launch": bool(vphase), "launches_per_iteration": launches, "spmv_kernel_mode_by_rank": rank_modes,
                            "hip_graph": bool(args.graph), "library": version},
                 "global_iterations_per_s": it_s,
                 "roofline": roofline_block(kern, d["moved"], d["alg"], d["spmv_us"], d["launches"], *tr),

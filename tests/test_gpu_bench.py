@@ -44,6 +44,7 @@ def test_more_ranks_and_both_data_planes(gpu, n_ranks, p2p):
     d, _ = run_bench("--gpus", str(n_ranks), "--transport", "host", "--steps", "10", "--n", "16", "--no-cpu",
                      env={"SB_P2P": p2p, "SB_P2P_HALO": p2p})
     assert d["n_gpus"] == n_ranks and d["value"] > 0
+    assert len(d["config"]["spmv_kernel_mode_by_rank"]) == n_ranks  # which SpMV kernel every rank's brick got
     if p2p == "0":
         assert d["config"]["dot_allreduce"] == "host_staged_gloo" and "SB_P2P=0" in d["config"]["dot_allreduce_reason"]
 
