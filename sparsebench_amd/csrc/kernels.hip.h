@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void waxpby_sdev_k(uint32_t n, const double* x
 // If x != NULL and the previous body left its "x = x + alpha p" (:127) pending, it is
 // applied here, where the old p is in registers anyway (saves one read of p per
 // iteration); the arithmetic and its order per element are unchanged.
-__global__ __launch_bounds__(256) void cg_update_p(uint32_t n, const double* __restrict__ r,
+__global__ __launch_bounds__(1024) void cg_update_p(uint32_t n, const double* __restrict__ r,
     double* p, double* x, const CgScalars* __restrict__ S, int which)
 {
   const uint32_t n2     = n >> 1;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void dot_spans_k(uint32_t n, const double* a, 
 // scalar step that follows reads n/256 doubles instead of n/64 (reduce_final_1024, l1).  The first group's loads go
 // in flight together with the stop flag / alpha instead of behind them.  Same arithmetic, same order, same bits as
 // a per-span r update followed by level1().
-__global__ __launch_bounds__(256) void cg_update_r_k(uint32_t n, const double* __restrict__ Ap, double* r,
+__global__ __launch_bounds__(1024) void cg_update_r_k(uint32_t n, const double* __restrict__ Ap, double* r,
     const CgScalars* __restrict__ S, double* __restrict__ l1out, const int* __restrict__ stop)
 {
   const uint32_t lane    = threadIdx.x & 63u;
