@@ -397,8 +397,9 @@ static void loop_body(sb_cg* s, int k)
     scalar_launch<1>(s, 1, s->partials2, 1);
     mark(s, R_DDOT);
   } else if (n) {
-    hipLaunchKernelGGL(waxpby_sdev_k, gridV, blockV, 0, g.stream, n, s->x, &s->S->alpha, s->p, s->x, stop);
-    hipLaunchKernelGGL(waxpby_sdev_k, gridV, blockV, 0, g.stream, n, s->r, &s->S->neg_alpha, s->Ap, s->r, stop);
+    const dim3 gridW(stream_grid(n / 2 + 1, 256)), blockW(256); // (the reference-shaped ops keep their 256-thread workgroups)
+    hipLaunchKernelGGL(waxpby_sdev_k, gridW, blockW, 0, g.stream, n, s->x, &s->S->alpha, s->p, s->x, stop);
+    hipLaunchKernelGGL(waxpby_sdev_k, gridW, blockW, 0, g.stream, n, s->r, &s->S->neg_alpha, s->Ap, s->r, stop);
     HIP_CHECK(hipGetLastError());
     mark(s, R_WAXPBY);
   }
