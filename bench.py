@@ -358,7 +358,7 @@ def run_rank(args):
     def measure(prob, modes):
         """timed passes on one resident matrix.  modes: kernel modes to time with per-launch events; the
         first is the one `value` is quoted on (clean pass without events)."""
-        cg = hostapi.CG(prob, fused=True, graph=bool(args.graph))
+        cg = hostapi.CG(prob, fused=args.fused, graph=bool(args.graph))
         nonlocal vphase, launches
         vphase, launches = cg.vector_phase(), cg.launches_per_body()
 
@@ -545,6 +545,8 @@ def main():
     ap.add_argument("--irr-sigmas", type=lambda s: [int(v) for v in s.split(",")], default=[1, 4096],
                     help="irregular: sorting scopes of the Sell-C-sigma legs")
     ap.add_argument("--graph", type=int, default=0)
+    ap.add_argument("--fused", type=int, default=1,
+                    help="sb_cg_set_fused level: 1 five launches per loop body (default), 2 / 3 / 4 the measured alternatives")
     ap.add_argument("--pack-mode", type=int, default=-1,
                     help="SpMV stream: 0 reference layout, 1 compressed, 2 compressed + LDS x-window, "
                          "3 pattern codes / row patterns + LDS x-window (default -1: the library's choice)")
