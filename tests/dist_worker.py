@@ -20,6 +20,8 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import pyoracle as po  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from irregular_locs import irregular_locs  # noqa: E402
 from sparsebench_amd import hostapi  # noqa: E402
 
 
@@ -71,19 +73,7 @@ def irregular_case(H, rank, size):
     neighbours) -> plan and renumbered matrix equal to the oracle's partition of the one-rank matrix's row slices"""
     n = 10
     prob = hostapi.Problem("irregular", n, n, n, fmt="crs", rank=rank, size=size, upload=False)
-    locs = []
-    for r in range(size):  # the oracle partitions row slices of the ONE-rank matrix (global column ids)
-        one = hostapi.Problem("irregular", n, n, n, fmt="crs", rank=0, size=1, upload=False)
-        rp = one.array("rowPtr").astype(np.int64)
-        col, val = one.gm_entries()
-        nr = one.nr
-        base, extra = nr // size, nr % size
-        lo = r * base + min(r, extra)
-        hi = lo + base + (1 if r < extra else 0)
-        g = po.GMatrix.from_csr((rp[lo:hi + 1] - rp[lo]).astype(np.uint32), col[rp[lo]:rp[hi]], val[rp[lo]:rp[hi]], nc=nr)
-        g.s.startRow, g.s.stopRow, g.s.totalNr = lo, hi - 1, nr
-        locs.append(g)
-        one.free()
+    locs = irregular_locs(n, size)  # the oracle partitions row slices of the ONE-rank matrix (global column ids)
     plans = po.Plans(locs)
     mine, g = plans.plan(rank), locs[rank]
     assert prob.nr == g.nr and prob.nc == g.nc, (prob.nc, g.nc)

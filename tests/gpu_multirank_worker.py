@@ -19,6 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import pyoracle as po  # noqa: E402
 from sparsebench_amd import capi, gloo_transport, hostapi  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from irregular_locs import irregular_locs  # noqa: E402
 
 vp = C.c_void_p
 
@@ -27,6 +29,7 @@ def main():
     dist.init_process_group("gloo")
     rank, size = dist.get_rank(), dist.get_world_size()
     fmt, Cc, sigma, n, itermax = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    workload = sys.argv[6] if len(sys.argv) > 6 else "generate"  # or "irregular": the configs[4] stand-in, n^3 nodes
     L = capi.init(0)  # every rank on the one GPU
     H = hostapi.host()
 
@@ -34,8 +37,9 @@ def main():
     # the host, gloo in between): sparsebench_amd/gloo_transport.py
     keep = gloo_transport.attach(L, H, dist, rank, size)  # noqa: F841  (ctypes callbacks must stay alive)
 
-    prob = hostapi.Problem("generate", n, n, n, fmt=fmt, Cc=Cc, sigma=sigma, rank=rank, size=size)
-    locs = [po.GMatrix.generate(n, n, n, r, size) for r in range(size)]
+    prob = hostapi.Problem(workload, n, n, n, fmt=fmt, Cc=Cc, sigma=sigma, rank=rank, size=size)
+    # (irregular: far couplings make every rank a neighbour of every other; general-matrix kernels, no pattern levels)
+    locs = irregular_locs(n, size) if workload == "irregular" else [po.GMatrix.generate(n, n, n, r, size) for r in range(size)]
     plans = po.Plans(locs)
     o = po.cg(locs, plans, itermax=itermax, fmt=fmt, Cc=Cc, sigma=sigma, dot="tree", rank_sum="tree", want_x=True)
     results = {}
@@ -65,7 +69,7 @@ def main():
             results[(mode, bool(fused))] = rr
     key = "hpcg%d_x%d" % (n, size)
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "cg_hist_mpi.json")))
-    if key in golden and golden[key]["itermax"] == itermax:
+    if workload == "generate" and key in golden and golden[key]["itermax"] == itermax:
         ref = np.array([float(v) for v in golden[key]["rr"]])
         rr = results[(0 if fmt == "crs" else 2 if (2, True) in results else 0, True)]
         live = ref / ref[0] >= 1e-20
@@ -84,6 +88,7 @@ def main():
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     assert torch.equal(lo, hi), "ranks disagree on the data plane: %r vs %r" % (lo.tolist(), hi.tolist())
     why, why_halo = L.sb_comm_p2p_reason().decode(), L.sb_halo_p2p_reason(prob.halo).decode()
+    prob_indegree = prob.indegree
     prob.free()
     L.sb_comm_finalize()
     if rank == 0:
@@ -92,6 +97,7 @@ def main():
         print("P2P_REASON", why, flush=True)
         print("HALO_P2P_REASON", why_halo, flush=True)
         print("GPU_MULTIRANK_OK", fmt, Cc, sigma, n, size, flush=True)
+        print("INDEGREE", prob_indegree, flush=True)
     dist.destroy_process_group()
 
 

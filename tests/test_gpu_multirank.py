@@ -77,6 +77,22 @@ def test_device_multirank_path(gpu, fmt, Cc, sigma, n, size, itermax, p2p):
             assert "VPHASE_RUNS 0" not in text, text[-2000:]
 
 
+@pytest.mark.parametrize("fmt,sigma", [("crs", 1), ("scs", 256)])
+def test_irregular_stand_in_on_three_ranks(gpu, fmt, sigma):
+    """configs[4]'s stand-in split over 3 ranks on the one GPU: its far couplings make every rank a neighbour of every
+    other (indegree 2), no pattern levels apply (native CRS / reference-layout Sell-64-sigma kernels inside the multi-rank
+    loop, the CRS one with the separate dot pass), halo push / pull and in-kernel all-reduce over peer-mapped memory.
+    History, x and residual bit-identical to the oracle's 3-rank run."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", SB_P2P="1", SB_P2P_REPORT="1", SB_VPHASE_MAXGRID="64")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "gpu_multirank_worker.py"), fmt, "64", str(sigma), "12", "40", "irregular"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-4000:]
+    assert "GPU_MULTIRANK_OK %s 64 %d 12 3" % (fmt, sigma) in text and "INDEGREE 2" in text, text[-3000:]
+
+
 def test_p2p_setup_failure_on_one_rank_falls_back_everywhere(gpu):
     """the in-kernel all-reduce is enabled collectively: if ONE rank cannot export / map its buffer, every
     rank must end up on the transport's all-reduce (no rank may wait in a kernel for a peer that never
