@@ -44,18 +44,45 @@ struct CgScalars {
 // ---- wave-level fixed-order reductions --------------------------------------
 // xor butterfly, offsets 1,2,4,...: every lane ends with the same value because
 // fp add is commutative.  This IS level 0 of the canonical dot.
-__device__ __forceinline__ double butterfly64(double v)
-{
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
-  return v;
+// The partner's value arrives by DPP moves (offsets 1, 2: quad_perm; 4: row_shl / row_shr by bank; 8: row_ror) and by
+// gfx950's v_permlane16_swap / v_permlane32_swap (offsets 16, 32: A' + B' of the swapped pair is own + partner in every
+// lane), not by __shfl_xor, which compiles to two ds_bpermute per step: 12 dependent LDS-pipe round trips per 64-bit
+// butterfly, 223 ns against 92 ns (tools/lab/butterfly_lab.hip, which also checks every step bit for bit) -- and in the
+// SpMV they sit at the very end of a tile's life, where nothing hides them.
+template <int CTRL, int BANKMASK> __device__ __forceinline__ double dpp_move(double old, double v)
+{ // lanes of the banks in BANKMASK: v of the lane CTRL names; the others: old
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v), o = __builtin_bit_cast(unsigned long long, old);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)b, CTRL, 0xF, BANKMASK, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(b >> 32), CTRL, 0xF, BANKMASK, false);
+  return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
 }
+template <int W> __device__ __forceinline__ double swap_add(double v)
+{ // v + (v of lane ^ W), W = 16 or 32
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const auto lo = W == 16 ? __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false)
+                          : __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+  const auto hi = W == 16 ? __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false)
+                          : __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+  const double A = __builtin_bit_cast(double, (unsigned long long)lo[0] | ((unsigned long long)hi[0] << 32));
+  const double B = __builtin_bit_cast(double, (unsigned long long)lo[1] | ((unsigned long long)hi[1] << 32));
+  return A + B;
+}
+__device__ __forceinline__ double butterfly16(double v)
+{ // offsets 1, 2, 4, 8
+  v = v + dpp_move<0xB1, 0xF>(v, v); // quad_perm [1,0,3,2]
+  v = v + dpp_move<0x4E, 0xF>(v, v); // quad_perm [2,3,0,1]
+  v = v + dpp_move<0x114, 0xA>(dpp_move<0x104, 0x5>(v, v), v); // banks 0,2: row_shl:4 (lane + 4); banks 1,3: row_shr:4 (lane - 4)
+  return v + dpp_move<0x128, 0xF>(v, v); // row_ror:8
+}
+__device__ __forceinline__ double butterfly64(double v) { return swap_add<32>(swap_add<16>(butterfly16(v))); }
 // half-wave form: lanes 0-31 and 32-63 each reduce their own 32 values
-__device__ __forceinline__ double butterfly32(double v)
+__device__ __forceinline__ double butterfly32(double v) { return swap_add<16>(butterfly16(v)); }
+// v of lane `lane` (compile-time constant) in every lane: v_readlane, no LDS-pipe trip
+template <int LANE> __device__ __forceinline__ double lane_value(double v)
 {
-#pragma unroll
-  for (int off = 1; off < 32; off <<= 1) v = v + __shfl_xor(v, off, 64);
-  return v;
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, LANE), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), LANE);
+  return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
 }
 
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an XCD and its
@@ -569,7 +596,7 @@ __global__ __launch_bounds__(1024) void cg_update_r_k(uint32_t n, const double* 
   if (stop && *stop) return;
   const double nalpha = -S->alpha;
   auto combine = [&](double t0, double t1) { // halves of t0: q0, q1; of t1: q2, q3
-    const double q0 = __shfl(t0, 0, 64), q1 = __shfl(t0, 32, 64), q2 = __shfl(t1, 0, 64), q3 = __shfl(t1, 32, 64);
+    const double q0 = lane_value<0>(t0), q1 = lane_value<32>(t0), q2 = lane_value<0>(t1), q3 = lane_value<32>(t1);
     return ((q0 + q1) + q2) + q3;
   };
   while (have) {
