@@ -27,7 +27,7 @@ SYMBOLS = [
     "sb_cg_history", "sb_cg_solution", "sb_cg_check_residual", "sb_cg_region_ms", "sb_version",
     "sb_comm_allgather_bytes", "sb_comm_alltoallv_ints", "sb_comm_barrier", "sb_cg_loop_ms",
     "sb_cg_spmv_timing", "sb_cg_spmv_ms", "sb_cg_counters", "sb_debug_stream_read_gbs",
-    "sb_matrix_pack_level", "sb_set_external_ids", "sb_matrix_use_packed", "sb_matrix_stream_bytes",
+    "sb_matrix_pack_level", "sb_set_external_ids", "sb_spmv_native_dot", "sb_matrix_use_packed", "sb_matrix_stream_bytes",
     "sb_matrix_packed_mode", "sb_matrix_lds_window", "sb_matrix_pattern_classes", "sb_matrix_row_patterns", "sb_matrix_row_programs", "sb_comm_p2p_handle", "sb_comm_p2p_open", "sb_comm_p2p_enabled", "sb_halo_p2p_enabled", "sb_cg_start", "sb_cg_finish", "sb_cg_vector_phase", "sb_cg_launches_per_body",
     "sb_comm_init_transport", "sb_comm_p2p_reason", "sb_halo_p2p_reason",
 ]
@@ -115,6 +115,7 @@ def load():
         "sb_matrix_pack_level": (C.c_int, [vp]),
         "sb_matrix_use_packed": (None, [vp, C.c_int]),
         "sb_set_external_ids": (None, [vp, C.c_uint32]),
+        "sb_spmv_native_dot": (C.c_int, [vp, vp, vp, vp]),
         "sb_matrix_stream_bytes": (C.c_double, [vp]),
         "sb_matrix_packed_mode": (C.c_int, [vp]),
         "sb_matrix_lds_window": (C.c_uint32, [vp]),

@@ -164,6 +164,14 @@ void sb_spmv_native(const sb_matrix* m, const double* x, double* y)
   launch_spmv(m, x, y, nullptr, nullptr);
 }
 
+int sb_spmv_native_dot(const sb_matrix* m, const double* x, double* y, double* partials_dev)
+{ // the product with the fused level-0 partials of x . y, as the CG loop launches it for p . Ap
+  need_init();
+  if (!(m->fmt == 1 ? m->C == 64 : spmv_uses_patterns(m))) return 0;
+  launch_spmv(m, x, y, partials_dev, nullptr);
+  return 1;
+}
+
 void sb_permute(const sb_matrix* m, const double* in_orig, double* out_perm)
 {
   need_init();

@@ -324,6 +324,37 @@ def test_waxpby_and_ddot_bit_exact(gpu, n):
         v.free()
 
 
+def test_fused_dot_partials_of_the_spmv(gpu):
+    """the p . Ap partials the CG loop takes out of the SpMV launch: per 64 rows (device order) the butterfly of x_i * y_i,
+    for every kernel mode with a fused dot -- level 1 of them equals the oracle's partials of the same two vectors"""
+    L = gpu
+    rng = np.random.default_rng(41)
+    for dims, sg in (((128, 128, 2), 256), ((32, 32, 32), 1), ((70, 3, 5), 1), ((20, 5, 33), 64)):
+        g = po.GMatrix.generate(*dims)
+        s = g.to_scs(64, sg)
+        m = upload_scs(L, s)
+        x = rng.standard_normal(g.nc)
+        xp = x[np.asarray(s.newToOldPerm)] if L.sb_matrix_is_permuted(m) else x  # the device's (permuted) order
+        dx, dy = DeviceVector.from_host(xp), DeviceVector(s.nr)
+        nq = 4 * ((s.nr + 255) // 256)
+        tried = set()
+        for mode in (5, 3, 2, 1, 0):
+            L.sb_matrix_use_packed(m, mode)
+            got = L.sb_matrix_packed_mode(m)
+            if got in tried:
+                continue
+            tried.add(got)
+            dq = DeviceVector.from_host(np.zeros(nq))
+            assert L.sb_spmv_native_dot(m, dx.ptr, dy.ptr, dq.ptr) == 1
+            y, q = dy.get(), dq.get().reshape(-1, 4)
+            lvl1 = ((q[:, 0] + q[:, 1]) + q[:, 2]) + q[:, 3]
+            assert np.array_equal(lvl1.view(np.uint64), po.ddot_partials(xp[:s.nr].copy(), y).view(np.uint64)), (dims, sg, got)
+            dq.free()
+        assert len(tried) >= 3
+        dx.free(), dy.free()
+        L.sb_matrix_free(m)
+
+
 def test_ddot_run_to_run_reproducible(gpu):
     L = gpu
     rng = np.random.default_rng(2)

@@ -38,6 +38,18 @@ for mode in modes:
         best = min(best, 1e3 * L.sb_event_elapsed_ms(a, b) / 100)
     print("%s mode %d: %.2f us  (moves %.1f MB)" % (os.environ.get("SBHIP_LIBRARY", "product"), mode, best,
                                                    L.sb_matrix_stream_bytes(m) / 1e6))
+    if hasattr(L, "sb_spmv_native_dot"):  # the same launch with the fused level-0 partials of x . y (what CG runs)
+        q = DeviceVector.from_host(np.zeros(4 * ((s.nr + 255) // 256)))
+        if L.sb_spmv_native_dot(m, x.ptr, y.ptr, q.ptr):
+            best = 1e9
+            for rep in range(3):
+                L.sb_event_record(a)
+                for _ in range(100):
+                    L.sb_spmv_native_dot(m, x.ptr, y.ptr, q.ptr)
+                L.sb_event_record(b)
+                best = min(best, 1e3 * L.sb_event_elapsed_ms(a, b) / 100)
+            print("   ... with the fused dot: %.2f us" % best)
+        q.free()
 
 # lab build with per-tile timestamps (sb_lab_prof): phases of the pattern kernel (the first of `modes`), in us
 if hasattr(L, "sb_lab_prof"):
