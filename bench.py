@@ -23,8 +23,20 @@ JSON line.
   roofline_reference_layout = the same for the kernel that streams the reference's own Sell-C-sigma /
                  CRS arrays (12 B per stored element) -- the figure north_star's ">= 60 % of the HBM
                  roofline" is about; algorithmic_speedup = its bytes / the default kernel's bytes.
+  roofline_reference_layout also carries a CLEAN (event-free) cg_iterations_per_s of the loop run on that
+                 kernel: `value` exploits the structure of the matrix (compressed mirror), that rate does not.
   cpu_baseline = the reference's own solveCG (oracle/_ref, upstream flags + OpenMP) timed on this box's
                  host cores on a bounded sample (rank 0, N=1)
+  preflight    = before anything is timed, every rank solves 20 CG iterations on a 32^3-per-rank problem and on
+                 the bench's own bricks and checks the history against closed-form known answers (r.r of the
+                 prologue, p.Ap of the first body: exact integers at any size and rank count,
+                 sparsebench_amd/knownanswers.py), against the committed oracle histories in the GPU's dot order
+                 (tests/golden/cg_hist_tree.json: bit for bit), and against every other rank's history (identical
+                 bits).  Any mismatch: no rate is printed, exit code 4.  At N > 1 this runs on BOTH data planes.
+  rccl_only    = (N > 1) the same K steps timed again with the peer-mapped paths switched off
+                 (sb_comm_data_plane(0): RCCL all-reduce + send/recv), so one invocation yields both curves.
+  phases_us    = per-kernel breakdown of a loop body from an event after every launch (a separate pass).
+  K < 100      : the K-step timing is repeated and the MEDIAN is reported (timed_repeats).
 
 `python bench.py --gpus N` works as typed: the parent process starts N rank processes (one per GPU,
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, free port) BEFORE anything touches the GPU, relays rank 0's
@@ -55,8 +67,11 @@ SEGMENT = 120          # iterations per timed segment (keeps r.r far from underf
 def pmc_traffic(workload, kernel, version):
     """HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, as the guide prescribes) of `kernel` on
     `workload`, from the newest committed profiles/*_pmc_traffic.json whose entry was collected with
-    THIS library version.  Returns (bytes, source, note): bytes is None -- never a stale constant --
-    when no pass matches, and the note says what is missing."""
+    THIS kernel source (content hash of sparsebench_amd/csrc/*, sparsebench_amd/srchash.py -- a kernel
+    edit invalidates the entry whether or not anybody bumped a version string).  Returns (bytes, source,
+    note): bytes is None -- never a stale constant -- when no pass matches, and the note says what is missing."""
+    from sparsebench_amd import srchash
+    version = srchash.csrc_hash()
     pdir = os.path.join(ROOT, "profiles")
     names = sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_traffic.json")), reverse=True) \
         if os.path.isdir(pdir) else []
@@ -69,10 +84,10 @@ def pmc_traffic(workload, kernel, version):
         e = doc.get(workload, {}).get(kernel)
         if not e:
             continue
-        if e.get("library_version", doc.get("library_version")) == version:
+        if e.get("source_hash", doc.get("source_hash")) == version:
             return e["bytes_per_launch"], "profiles/" + name, None
-        stale = stale or "profiles/%s holds %s/%s for library %r, not %r" % (
-            name, workload, kernel, e.get("library_version", doc.get("library_version")), version)
+        stale = stale or "profiles/%s holds %s/%s for kernel source %r, the library was built from %r" % (
+            name, workload, kernel, e.get("source_hash", doc.get("source_hash")), version)
     note = stale or "no committed PMC pass for %s / %s" % (workload, kernel)
     sys.stderr.write("bench: roofline.traffic = null: %s\n" % note)
     return None, None, note
@@ -135,6 +150,7 @@ def cpu_baseline_child(workload, n, iters):
                 "sample": "irregular %d^3 nodes CRS, %d CG loop bodies, 1 rank x %d OpenMP threads" % (n, iters, thr.value)}
     sample = "HPCG %d^3 CRS, %d CG loop bodies (difference of two solveCG runs: set-up, prologue and residual check " \
              "cancel), 1 rank x %d OpenMP threads" % (n, iters, threads)
+    why = "oracle/_ref/libsbref_crs_omp.so is not in this tree (the reference build did not travel)"
     try:
         if po.ref_available("crs_omp"):
             ref = po.Ref("crs_omp")
@@ -150,14 +166,22 @@ def cpu_baseline_child(workload, n, iters):
             if dt > 0 and k2 > k1:
                 return {"value": (k2 - k1) / dt, "unit": "iterations/s", "cores": threads, "kind": "reference",
                         "sample": sample}
+            # (small problems: both runs are dominated by set-up noise and the difference can come out <= 0)
+            if k2 > 0 and t2 - t1 > 0:
+                return {"value": k2 / (t2 - t1), "unit": "iterations/s", "cores": threads, "kind": "reference",
+                        "sample": sample.replace("difference of two solveCG runs: set-up, prologue and residual check cancel",
+                                                 "ONE solveCG run incl. its prologue and residual check: the two-run difference "
+                                                 "was not positive at this size (%.3f s vs %.3f s)" % (t1 - t0, t2 - t1))}
+            why = "the reference's solveCG returned no iterations (k = %d, %d)" % (k1, k2)
     except Exception as e:  # fall through to the port
-        sys.stderr.write("cpu_baseline: reference leg failed (%s), using the port\n" % e)
+        why = "the reference leg failed: %s" % e
+    sys.stderr.write("cpu_baseline: kind 'port' because %s\n" % why)
     with quiet_stdout():
         g = po.GMatrix.generate(n, n, n)
         thr = ctypes.c_int(0)
         dt = po.lib().orc_time_cg_iters(g.ptr, iters, ctypes.byref(thr))
-    return {"value": iters / dt, "unit": "iterations/s", "cores": thr.value, "kind": "port",
-            "sample": sample.replace("the reference's own timeStart/timeStop", "the port")}
+    return {"value": iters / dt, "unit": "iterations/s", "cores": thr.value, "kind": "port", "why_port": why,
+            "sample": "HPCG %d^3 CRS, %d CG loop bodies of the oracle's OpenMP restatement, 1 rank x %d threads" % (n, iters, thr.value)}
 
 
 def cpu_mpi_leg(n, iters, cores):
@@ -244,8 +268,11 @@ def free_port():
 
 def spawn_ranks(n_gpus, argv):
     """One child per rank; this process never touches the GPU (no HIP call, no exec of a process that
-    has).  Rank 0's stdout is captured and its single JSON line relayed; the others' stdout goes to
-    stderr.  Exit code = the first non-zero child exit code."""
+    has).  Rank 0's stdout is captured (reader thread) and its single JSON line relayed; the others'
+    stdout goes to stderr.  ALL children are polled: as soon as one exits non-zero the others -- which
+    would otherwise sit in a collective that has no time-out -- are terminated, and that rank's exit code
+    is returned.  Nothing is ever restarted or exec'd."""
+    import threading
     port = free_port()
     procs = []
     for r in range(n_gpus):
@@ -254,18 +281,34 @@ def spawn_ranks(n_gpus, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0 = b""
-    rc = 0
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc, failed = 0, None
     try:
-        out0, _ = procs[0].communicate()
-        for p in procs:
-            code = p.wait()
-            if code != 0 and rc == 0:
-                rc = code
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed, rc = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(0.05)
     finally:
-        for p in procs:  # a rank that died leaves the others waiting in a collective: end exactly those we started
+        if failed is not None:
+            sys.stderr.write("bench: rank %d exited with code %d; ending the other ranks\n" % (failed, rc))
+            time.sleep(1.0)  # (let ranks that are failing for the same reason print their own message)
+        for p in procs:  # end exactly the processes we started
             if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
                 p.kill()
+    reader.join(timeout=10)
+    out0 = b"".join(c for c in chunks if c)
     lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.startswith("{")]
     if lines:
         print(lines[-1], flush=True)
@@ -273,6 +316,58 @@ def spawn_ranks(n_gpus, argv):
         rc = 3
         sys.stderr.write("bench: rank 0 printed no JSON line\n")
     return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# pre-flight: known answers before anything is timed
+# ------------------------------------------------------------------------------------------------
+PREFLIGHT_ITERS = 20   # itermax of the pre-flight solves (and of the committed P-rank goldens)
+PREFLIGHT_SMALL = 32   # brick edge of the small pre-flight problem
+
+
+def golden_key(n, P, fmt, Cc, sigma):
+    return "hpcg%d_x%d_%s" % (n, P, "crs" if fmt == "crs" else "scs_C%d_sigma%d" % (Cc, sigma))
+
+
+def load_goldens():
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "cg_hist_tree.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def check_history(label, rr, pap, n, world, key, goldens):
+    """One pre-flight solve against what is known about it.  Returns (record, problems)."""
+    import numpy as np
+    from sparsebench_amd import knownanswers as ka
+    rec = {"case": label, "iterations": int(len(pap))}
+    bad = []
+    want_rr0, want_pap1 = float(ka.hpcg_rr0(n, n, n * world)), float(ka.hpcg_pAp1(n, n, n * world))
+    if len(rr) < 2 or len(pap) < 1:
+        return rec, ["%s: the solve produced no history (%d r.r, %d p.Ap values)" % (label, len(rr), len(pap))]
+    rec["rr0"], rec["rr0_closed_form"] = float(rr[0]), want_rr0
+    rec["pAp1"], rec["pAp1_closed_form"] = float(pap[0]), want_pap1
+    if rr[0] != want_rr0:
+        bad.append("%s: r.r of the prologue is %.17g, closed form %.17g" % (label, rr[0], want_rr0))
+    if pap[0] != want_pap1:
+        bad.append("%s: p.Ap of the first body is %.17g, closed form %.17g (first product that needs the halo)" % (label, pap[0], want_pap1))
+    if not (np.all(np.isfinite(rr)) and np.all(np.isfinite(pap)) and np.all(pap > 0) and np.all(rr > 0)):
+        bad.append("%s: the history holds non-finite or non-positive values" % label)
+    g = goldens.get(key)
+    rec["golden"] = key if g else None
+    if g:
+        grr = np.array([float(v) for v in g["rr"]])
+        gpa = np.array([float(v) for v in g["pAp"]])
+        m, q = min(len(grr), len(rr)), min(len(gpa), len(pap))
+        if m < PREFLIGHT_ITERS - 2 or q < PREFLIGHT_ITERS - 2:
+            bad.append("%s: only %d / %d values to compare with the golden history" % (label, m, q))
+        elif not (np.array_equal(rr[:m], grr[:m]) and np.array_equal(pap[:q], gpa[:q])):
+            d = np.nonzero(rr[:m] != grr[:m])[0]
+            e = np.nonzero(pap[:q] != gpa[:q])[0]
+            bad.append("%s: history differs from tests/golden/cg_hist_tree.json[%s]: first r.r mismatch at %s, first p.Ap "
+                       "mismatch at %s" % (label, key, d[0] if len(d) else None, e[0] if len(e) else None))
+        rec["golden_values_compared"] = int(m + q)
+    return rec, bad
 
 
 # ------------------------------------------------------------------------------------------------
@@ -299,7 +394,7 @@ def roofline_block(kernel, moved, alg, us, launches, traffic, traffic_src, traff
 
 
 def run_rank(args):
-    import numpy as np  # noqa: F401
+    import numpy as np
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -321,10 +416,15 @@ def run_rank(args):
             dist.init_process_group("gloo", rank=rank, world_size=world)
             dist.barrier()
 
+    if os.environ.get("SB_BENCH_TEST_DIE_RANK") == str(rank):  # test hook: a rank that dies before the first collective
+        sys.stderr.write("bench: rank %d: SB_BENCH_TEST_DIE_RANK is set, exiting with code 7 (test hook)\n" % rank)
+        os._exit(7)
+
     from sparsebench_amd import capi, hostapi
     capi.load()
     ndev = capi.load().sb_device_count()
-    L = capi.init(local % ndev if args.transport == "host" and ndev > 0 else local)
+    device = local % ndev if args.transport == "host" and ndev > 0 else local
+    L = capi.init(device)
     if world > max(ndev, 1):  # ranks share GPUs (rehearsal): the one-launch vector phase needs a GPU to itself
         os.environ.setdefault("SB_SHARED_GPU", "1")
     H = hostapi.host()
@@ -352,26 +452,102 @@ def run_rank(args):
             dist.barrier()
         L.sb_sync()
 
+    def gather(obj):
+        """every rank's `obj`, in rank order"""
+        if dist is None:
+            return [obj]
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+
+    def rank_max(v):
+        if dist is None:
+            return float(v)
+        import torch
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
     K, W = args.steps, args.warmup
+    repeats = 1 if K >= 100 else 9  # a 1 ms window moves by a few per cent from run to run: median of 9
     vphase, launches = 0, 5
 
-    def measure(prob, modes):
+    # ---- pre-flight ------------------------------------------------------------------------------------
+    goldens = load_goldens()
+
+    def preflight(plane_name, prob_full):
+        """20 CG iterations on a 32^3-per-rank problem and on the bench's own bricks, on the data plane that is
+        selected right now.  Collective; returns (records, problems) identical on every rank."""
+        import hashlib
+        records, problems = [], []
+        cases = [("%s: 32^3 per rank" % plane_name, PREFLIGHT_SMALL, None)]
+        if n != PREFLIGHT_SMALL:
+            cases.append(("%s: bench bricks (%d^3 per rank)" % (plane_name, n), n, prob_full))
+        else:
+            cases = [("%s: bench bricks (32^3 per rank)" % plane_name, n, prob_full)]
+        for label, nn, pr in cases:
+            own = pr is None
+            if own:
+                with quiet_stdout():
+                    pr = hostapi.Problem("generate", nn, nn, nn, fmt=args.fmt, Cc=args.C, sigma=args.sigma, rank=rank, size=world)
+            cg = hostapi.CG(pr, fused=args.fused, graph=False)
+            cg.solve(PREFLIGHT_ITERS, 0.0)
+            rr, pap = cg.history()
+            cg.free()
+            if own:
+                pr.free()
+            rec, bad = check_history(label, rr, pap, nn, world, golden_key(nn, world, args.fmt, args.C, args.sigma), goldens)
+            digest = hashlib.sha256(rr.tobytes() + pap.tobytes()).hexdigest()[:16]
+            everyone = gather((digest, bad))
+            digests = [d for d, _ in everyone]
+            rec["history_sha256_by_rank"] = digests
+            if len(set(digests)) != 1:
+                bad = bad + ["%s: the ranks hold DIFFERENT histories (all-reduced scalars must be identical bits): %s" % (label, digests)]
+            for r, (_, b) in enumerate(everyone):  # a problem seen by any rank is everybody's problem
+                for msg in b:
+                    if msg not in bad:
+                        bad.append("rank %d: %s" % (r, msg))
+            rec["ok"] = not bad
+            records.append(rec)
+            problems += bad
+        return records, problems
+
+    def fail_preflight(records, problems, workload):
+        if rank == 0:
+            for msg in problems:
+                sys.stderr.write("bench: PRE-FLIGHT FAILED: %s\n" % msg)
+            print(json.dumps({"metric": "cg_iterations_per_s", "value": None, "unit": "iterations/s", "n_gpus": world,
+                              "steps": K, "warmup": W, "error": "pre-flight check failed: nothing was timed",
+                              "config": {"workload": workload},
+                              "preflight": {"ok": False, "problems": problems, "checks": records}}), flush=True)
+        if world > 1:
+            L.sb_sync()
+            dist.barrier()
+        # (no sb_comm_finalize / destroy_process_group: the run is invalid, leave at once with the failure code)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(4)
+
+    def measure(prob, modes, clean_all=False, phases=True):
         """timed passes on one resident matrix.  modes: kernel modes to time with per-launch events; the
-        first is the one `value` is quoted on (clean pass without events)."""
+        first is the one `value` is quoted on.  Every mode gets a clean pass (no events) when clean_all."""
         cg = hostapi.CG(prob, fused=args.fused, graph=bool(args.graph))
         nonlocal vphase, launches
         vphase, launches = cg.vector_phase(), cg.launches_per_body()
 
-        def timed_pass(with_spmv_events):
+        def timed_pass(with_spmv_events, with_phases=False):
             """exactly K loop bodies, in segments restarted from x0 = 0 outside the clock"""
             total, left, spmv_ms, spmv_n = 0.0, K, 0.0, 0
+            phase_acc = {}
             while left > 0:
                 seg = min(left, SEGMENT)
                 cg.spmv_timing(False)
+                cg.phase_timing(False)
                 cg.start(itermax=W + 2 + seg, eps=0.0)  # prologue
                 cg.run_iters(W + 1)                     # warm-up bodies, untimed
                 before = cg.counters()
                 cg.spmv_timing(with_spmv_events)
+                cg.phase_timing(with_phases)
                 barrier()
                 t0 = time.perf_counter()
                 cg.run_iters(seg)
@@ -380,6 +556,12 @@ def run_rank(args):
                 barrier()    # ... and nobody moves on before all are (the max over ranks is taken below;
                 #                 the gloo TCP barrier itself is control plane, not part of a CG step)
                 after = cg.counters()
+                if with_phases:
+                    for name, (us, cnt) in cg.phase_us().items():
+                        a = phase_acc.setdefault(name, [0.0, 0])
+                        a[0] += us * cnt
+                        a[1] += cnt
+                cg.phase_timing(False)
                 cg.finish()
                 if after["stop"] and after["iters"] != W + 1 + seg:
                     raise RuntimeError("bench: the loop exited early: %r" % after)
@@ -391,22 +573,29 @@ def run_rank(args):
                     spmv_n += cnt
                 total += dt
                 left -= seg
-            return total, spmv_ms, spmv_n
+            return total, spmv_ms, spmv_n, {k: (v[0] / v[1], v[1] // max(1, K)) for k, v in phase_acc.items() if v[1]}
 
         res = {}
         for i, mode in enumerate(modes):
             got = prob.use_packed(mode)
             if got != mode:
                 continue
-            t_clean = timed_pass(False)[0] if i == 0 or args.all_clean else None
-            t_ev, ms, cnt = timed_pass(True)
-            if t_clean is not None and dist is not None:
-                import torch
-                tt = torch.tensor([t_clean], dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                t_clean = float(tt[0])
-            res[mode] = {"t_clean": t_clean, "t_ev": t_ev, "spmv_us": 1e3 * ms / max(cnt, 1), "launches": cnt,
-                         "moved": prob.stream_bytes(), "alg": prob.spmv_bytes()}
+            t_clean = t_mine = None
+            all_reps = []
+            if i == 0 or clean_all:
+                mine, agreed = [], []
+                for _ in range(repeats):
+                    dt = timed_pass(False)[0]
+                    mine.append(dt)
+                    agreed.append(rank_max(dt))  # the step ends when the slowest rank is done
+                order = sorted(range(repeats), key=lambda j: agreed[j])
+                mid = order[repeats // 2]        # the median repeat (the same one on every rank)
+                t_clean, t_mine, all_reps = agreed[mid], mine[mid], agreed
+            t_ev, ms, cnt, _ = timed_pass(True)
+            ph = timed_pass(False, True)[3] if phases and (i == 0 or clean_all) else None
+            res[mode] = {"t_clean": t_clean, "t_mine": t_mine, "t_repeats": all_reps, "t_ev": t_ev,
+                         "spmv_us": 1e3 * ms / max(cnt, 1), "launches": cnt,
+                         "moved": prob.stream_bytes(), "alg": prob.spmv_bytes(), "phases": ph}
         prob.use_packed(modes[0])
         cg.free()
         return res
@@ -417,28 +606,60 @@ def run_rank(args):
         read and r, p, x written once: 56 B/row.  Plus the partials written and read back."""
         return (56.0 if vphase else 64.0) * nr + 2 * 8.0 * (nr / 64.0)
 
+    def phase_table(ph):
+        return {k: round(v[0], 3) for k, v in ph.items()} if ph else None
+
     out = None
     if not irregular:
         with quiet_stdout():
             prob = hostapi.Problem("generate", n, n, n, fmt=args.fmt, Cc=args.C, sigma=args.sigma, rank=rank, size=world)
         default = prob.use_packed(args.pack_mode) if args.pack_mode >= 0 else prob.pack_info()["mode"]
+        workload = "hpcg_27pt_%d^3_per_gpu_%s_C%d_sigma%d" % (n, args.fmt, args.C, args.sigma)
+        p2p_dots, p2p_halo = (L.sb_comm_p2p_enabled(), L.sb_halo_p2p_enabled(prob.halo)) if world > 1 else (0, 0)
+        second_plane = world > 1 and (p2p_dots or p2p_halo) and not args.no_rccl_leg
+        coll = "rccl" if args.transport == "rccl" else "host_staged_gloo"
+
+        # pre-flight on every data plane that will be timed, before anything is timed
+        checks, problems = [], []
+        if not args.no_preflight:
+            for plane in ([1, 0] if second_plane else [1]):
+                if world > 1:
+                    L.sb_comm_data_plane(plane)
+                name = "one GPU" if world == 1 else ("peer-mapped data plane" if plane and (p2p_dots or p2p_halo) else "%s data plane" % coll)
+                recs, bad = preflight(name, prob)
+                checks += recs
+                problems += bad
+            if world > 1:
+                L.sb_comm_data_plane(1)
+            if problems:
+                fail_preflight(checks, problems, workload)
+
         modes = [default] + ([0] if default != 0 else [])
-        res = measure(prob, modes)
-        rank_modes = [default]
-        if dist is not None:  # which SpMV kernel every rank ran (rank-local matrices differ: halo above / below / both)
-            import torch
-            mine = torch.tensor([default], dtype=torch.int32)
-            got = [torch.zeros(1, dtype=torch.int32) for _ in range(world)]
-            dist.all_gather(got, mine)
-            rank_modes = [int(t[0]) for t in got]
+        res = measure(prob, modes, clean_all=(world == 1) or args.all_clean)
+        res_coll = None
+        if second_plane:  # the same K steps on the communicator's collectives (RCCL all-reduce + send/recv)
+            L.sb_comm_data_plane(0)
+            res_coll = measure(prob, [default])
+            launches_coll = launches
+            L.sb_comm_data_plane(1)
+            launches = None  # (set again below from the default plane's solver)
+            cg_tmp = hostapi.CG(prob, fused=args.fused)
+            launches, vphase = cg_tmp.launches_per_body(), cg_tmp.vector_phase()
+            cg_tmp.free()
+        rccl = (ctypes.c_int * 3)()
+        has_rccl = L.sb_comm_rccl_info(rccl) if world > 1 else 0
+        per_rank = gather({"rank": rank, "device": device, "spmv_mode": default, "ms_per_step": 1e3 * res[default]["t_mine"] / K,
+                           "rccl": list(rccl) if has_rccl else None, "phases_us": phase_table(res[default]["phases"]),
+                           "ms_per_step_rccl_only": (1e3 * res_coll[default]["t_mine"] / K) if res_coll else None,
+                           "phases_us_rccl_only": phase_table(res_coll[default]["phases"]) if res_coll else None})
         if rank == 0:
             d = res[default]
             it_s = K / d["t_clean"]
-            workload = "hpcg_27pt_%d^3_per_gpu_%s_C%d_sigma%d" % (n, args.fmt, args.C, args.sigma)
             kern = kernel_name(args.fmt, default)
             tr = pmc_traffic(workload, kern, version) if world == 1 else (None, None, "N > 1")
             cg_moved = d["moved"] + vector_bytes(prob.nr)
             cg_alg = 96.0 * prob.nr + d["alg"]  # SURVEY 8d: reference's unfused op list on its own layout
+            steps_ms = [r["ms_per_step"] for r in per_rank]
             out = {
                 "metric": "cg_iterations_per_s",
                 "value": world * it_s,
@@ -452,15 +673,20 @@ def run_rank(args):
                            "parallelism": "1d_block_row_x%d" % world,
                            "transport": ("none" if world == 1 else "rccl_xgmi" if args.transport == "rccl"
                                          else "host_staged_gloo (rehearsal)"),
-                           "halo_exchange": ("none" if world == 1 else "peer_mapped_push_pull" if L.sb_halo_p2p_enabled(prob.halo)
+                           "halo_exchange": ("none" if world == 1 else "peer_mapped_push_pull" if p2p_halo
                                              else "rccl_send_recv" if args.transport == "rccl" else "host_staged_gloo"),
-                           "dot_allreduce": ("none" if world == 1 else "in_kernel_peer_mapped" if L.sb_comm_p2p_enabled()
+                           "dot_allreduce": ("none" if world == 1 else "in_kernel_peer_mapped" if p2p_dots
                                              else "rccl" if args.transport == "rccl" else "host_staged_gloo"),
                            "dot_allreduce_reason": (L.sb_comm_p2p_reason().decode() if world > 1 else None),
                            "halo_exchange_reason": (L.sb_halo_p2p_reason(prob.halo).decode() if world > 1 else None),
+                           "rccl_ranks": (rccl[0] if has_rccl else None),
                            "spmv_x_staging": ("lds_window" if default >= 2 else "l1_l2_gather (LDS staging measured neutral at 12 B/element)"),
-                           "fused_dots": True, "vector_phase_one_launch": bool(vphase), "launches_per_iteration": launches, "spmv_kernel_mode_by_rank": rank_modes,
+                           "fused_dots": True, "vector_phase_one_launch": bool(vphase), "launches_per_iteration": launches,
+                           "spmv_kernel_mode_by_rank": [r["spmv_mode"] for r in per_rank],
+                           "device_by_rank": [r["device"] for r in per_rank],
                            "hip_graph": bool(args.graph), "library": version},
+                "timed_repeats": repeats,
+                "ms_per_step_repeats": [1e3 * t / K for t in d["t_repeats"]],
                 "global_iterations_per_s": it_s,
                 "roofline": roofline_block(kern, d["moved"], d["alg"], d["spmv_us"], d["launches"], *tr),
                 "algorithmic_speedup": d["alg"] / d["moved"],
@@ -469,19 +695,54 @@ def run_rank(args):
                 "cg_frac_of_hbm_peak": cg_moved * it_s / 1e9 / HBM_PEAK_GBS,
                 "cg_reference_oplist_bytes_per_iteration": cg_alg,
                 "ms_per_step_with_events": 1e3 * d["t_ev"] / K,
+                "phases_us": phase_table(d["phases"]),
+                "preflight": ({"ok": True, "checks": checks} if not args.no_preflight else {"ok": None, "skipped": "--no-preflight"}),
                 "compression": prob.pack_info(),
                 "device": L.sb_device_name().decode(),
             }
+            if world > 1:
+                out["per_rank"] = {"ms_per_step": steps_ms, "ms_per_step_min": min(steps_ms), "ms_per_step_max": max(steps_ms),
+                                   "device": [r["device"] for r in per_rank], "rccl": [r["rccl"] for r in per_rank],
+                                   "phases_us": [r["phases_us"] for r in per_rank]}
+                ph_all = [r["phases_us"] for r in per_rank if r["phases_us"]]
+                if ph_all:
+                    out["phases_us_max_over_ranks"] = {k: max(p.get(k, 0.0) for p in ph_all) for k in ph_all[0]}
             out["roofline"]["note"] = (
                 "bytes = what this kernel streams (lossless compressed mirror, %.1f MB instead of the reference layout's "
-                "%.1f MB): a real HBM fraction; the reference-layout kernel is roofline_reference_layout" % (
+                "%.1f MB): a real HBM fraction on MOVED bytes -- this kernel exploits the structure of the matrix (repeating row "
+                "shapes); the kernel that streams the reference's arrays, and the loop run on it, is roofline_reference_layout" % (
                     d["moved"] / 1e6, d["alg"] / 1e6) if default > 0 else "kernel streams the reference layout: bytes = SURVEY 8d")
             if default != 0 and 0 in res:
                 r0 = res[0]
                 k0 = kernel_name(args.fmt, 0)
                 tr0 = pmc_traffic(workload, k0, version) if world == 1 else (None, None, "N > 1")
-                out["roofline_reference_layout"] = roofline_block(k0, r0["moved"], r0["alg"], r0["spmv_us"], r0["launches"], *tr0)
-                out["roofline_reference_layout"]["cg_iterations_per_s_with_events"] = world * K / r0["t_ev"]
+                blk = roofline_block(k0, r0["moved"], r0["alg"], r0["spmv_us"], r0["launches"], *tr0)
+                blk["cg_iterations_per_s_with_events"] = world * K / r0["t_ev"]
+                if r0["t_clean"]:
+                    blk["cg_iterations_per_s"] = world * K / r0["t_clean"]
+                    blk["ms_per_step"] = 1e3 * r0["t_clean"] / K
+                    cgm = r0["moved"] + vector_bytes(prob.nr)
+                    blk["cg_frac_of_hbm_peak"] = cgm * (K / r0["t_clean"]) / 1e9 / HBM_PEAK_GBS
+                    blk["phases_us"] = phase_table(r0["phases"])
+                blk["note"] = ("the loop with the SpMV streaming the reference's own Sell-C-sigma / CRS arrays (12 B per stored element): "
+                               "bytes = SURVEY 8d's algorithmic figure, no use of the matrix's structure; `value` is the same loop on the "
+                               "compressed mirror")
+                out["roofline_reference_layout"] = blk
+            if res_coll:
+                c = res_coll[default]
+                cm = [r["ms_per_step_rccl_only"] for r in per_rank]
+                out["rccl_only"] = {
+                    "value": world * K / c["t_clean"], "ms_per_step": 1e3 * c["t_clean"] / K,
+                    "ms_per_step_repeats": [1e3 * t / K for t in c["t_repeats"]],
+                    "halo_exchange": "rccl_send_recv" if args.transport == "rccl" else "host_staged_gloo",
+                    "dot_allreduce": coll, "launches_per_iteration": launches_coll,
+                    "per_rank_ms_per_step": cm, "phases_us": phase_table(c["phases"]),
+                    "phases_us_by_rank": [r["phases_us_rccl_only"] for r in per_rank],
+                    "note": "same bricks, same K steps, peer-mapped paths switched off (sb_comm_data_plane(0)): the communicator's "
+                            "all-reduce and send/recv carry the dots and the halo"}
+            elif world > 1:
+                out["rccl_only"] = {"note": "not timed separately: " + (
+                    "--no-rccl-leg" if args.no_rccl_leg else "the peer-mapped paths are off, `value` IS the communicator's data plane")}
         prob.free()
     else:
         if world != 1:
@@ -499,13 +760,15 @@ def run_rank(args):
             workload = "irregular_fe_%d^3_nodes_%s" % (n, name)
             kern = kernel_name(fmt, default)
             tr = pmc_traffic(workload, kern, version)
-            # (the native CRS kernel has no fused p.Ap: the loop adds a dot pass over p and Ap)
-            cg_moved = d["moved"] + vector_bytes(prob.nr) + (16.0 * prob.nr if fmt == "crs" and default == 0 else 0.0)
+            # (a native CRS kernel without the fused p.Ap adds a dot pass over p and Ap: 16 B/row)
+            dot_pass = bool(d["phases"] and "dot_pass" in d["phases"])
+            cg_moved = d["moved"] + vector_bytes(prob.nr) + (16.0 * prob.nr if dot_pass else 0.0)
             formats[name] = {
                 "cg_iterations_per_s": K / d["t_clean"], "ms_per_step": 1e3 * d["t_clean"] / K,
                 "fill": (prob.nnzTrue / prob.nElems) if fmt == "scs" else 1.0,
                 "roofline": roofline_block(kern, d["moved"], d["alg"], d["spmv_us"], d["launches"], *tr),
                 "spmv_useful_GBs": (12.0 * prob.nnzTrue + 16.0 * prob.nr) / (d["spmv_us"] * 1e-6) / 1e9,
+                "separate_dot_pass": dot_pass, "phases_us": phase_table(d["phases"]),
                 "cg_frac_of_hbm_peak": cg_moved * (K / d["t_clean"]) / 1e9 / HBM_PEAK_GBS}
             if best is None or formats[name]["cg_iterations_per_s"] > formats[best]["cg_iterations_per_s"]:
                 best = name
@@ -520,6 +783,7 @@ def run_rank(args):
                                    "host/sbh_irregular.c), best format: %s" % (n, best),
                        "rows_per_gpu": meta["rows"], "nnz_per_gpu": meta["nnz"], "index_type": "u32",
                        "parallelism": "1d_block_row_x1", "library": version},
+            "timed_repeats": repeats,
             "roofline": b["roofline"], "formats": formats, "device": L.sb_device_name().decode(),
         }
 
@@ -546,14 +810,18 @@ def main():
                     help="irregular: sorting scopes of the Sell-C-sigma legs")
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--fused", type=int, default=1,
-                    help="sb_cg_set_fused level: 1 five launches per loop body (default), 2 / 3 / 4 the measured alternatives")
+                    help="sb_cg_set_fused level: 1 five launches per loop body (default); 0 the reference's op list; "
+                         "2 / 3 the measured-slower alternatives (lab builds only)")
     ap.add_argument("--pack-mode", type=int, default=-1,
-                    help="SpMV stream: 0 reference layout, 1 compressed, 2 compressed + LDS x-window, "
-                         "3 pattern codes / row patterns + LDS x-window (default -1: the library's choice)")
+                    help="SpMV stream: 0 reference layout, 5 masked row programs + LDS x-window where the matrix qualifies "
+                         "(default -1: the library's choice); 1-3 intermediate forms (lab builds only)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
                     help="N > 1 data plane: rccl (production) or host (gloo-staged; lets N ranks share one GPU "
                          "to rehearse the multi-rank flow -- its numbers are not a benchmark)")
-    ap.add_argument("--all-clean", action="store_true", help="also time the secondary kernel modes without events")
+    ap.add_argument("--all-clean", action="store_true", help="N > 1: also time the reference-layout kernel without events "
+                                                             "(N = 1 always does)")
+    ap.add_argument("--no-rccl-leg", action="store_true", help="N > 1: do not time the second data plane (rccl_only)")
+    ap.add_argument("--no-preflight", action="store_true", help="skip the known-answer checks (lab use; the line says so)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=60)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)

@@ -181,6 +181,16 @@ int sb_comm_p2p_enabled(void);
 /* one line saying why the path is on or off (which rank, which call failed, what the self-test saw);
  * waits inside CG are bounded by SB_P2P_TIMEOUT_MS (default 30000), the set-up self-tests by 5 s */
 const char* sb_comm_p2p_reason(void);
+/* Which data plane the CG loop uses from now on: 1 (default) the peer-mapped paths where their set-up succeeded,
+ * 0 the communicator's own collectives (all-reduce, send / recv: src/comm.c:640-648,659) although the mappings
+ * exist -- as SB_P2P=0 SB_P2P_HALO=0 would have given, nothing torn down, so one process can time both (bench.py).
+ * Collective by contract: every rank calls it with the same value, between solves; solver objects are created
+ * after the switch. */
+void sb_comm_data_plane(int peer_mapped);
+int sb_comm_data_plane_selected(void);
+/* what the RCCL communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice):
+ * out = {ranks, this rank, HIP device}; returns 0 (out = -1) without an RCCL communicator */
+int sb_comm_rccl_info(int out[3]);
 void sb_comm_finalize(void);
 int sb_comm_rank(void);
 int sb_comm_size(void);
@@ -196,6 +206,8 @@ void sb_comm_alltoallv_ints(const int* sendbuf, const int* sendcounts, const int
 void sb_comm_barrier(void);
 /* device side of commPartition's result, src/comm.h:27-46: neighbour lists and
  * elementsToSend become device arrays.  perm_of_row may be NULL (identity). */
+/* (test hook: SB_TEST_CORRUPT_HALO=r makes rank r send a wrong row's value in its first halo slot, announced on
+ * stderr -- bench.py's pre-flight gate must catch it) */
 sb_halo* sb_halo_create(uint32_t nr, int outdegree, const int* destinations,
                         const int* sendCounts, const int* sdispls, int indegree,
                         const int* sources, const int* recvCounts, const int* rdispls,
@@ -257,6 +269,14 @@ double sb_cg_loop_ms(const sb_cg* s);
  * layer's stream; sb_cg_spmv_ms returns their summed duration and count */
 void sb_cg_spmv_timing(sb_cg* s, int on);
 double sb_cg_spmv_ms(sb_cg* s, int* launches);
+/* per-kernel breakdown of the loop: an event after every launch of a loop body.  sb_cg_phase_ms returns the number
+ * of phases P <= 8 and fills ms_out[i] / count_out[i] (summed milliseconds, occurrences) since timing was switched on:
+ * 0 p update (+ owed x update), 1 halo (push kernel, or pack + send/recv), 2 SpMV (+ fused p.Ap partials; with the
+ * peer-mapped halo: incl. the wait for the neighbours' pushes), 3 alpha step (levels 1-2 of p.Ap [+ all-reduce] +
+ * alpha), 4 r update (+ r.r partials), 5 beta step / loop test (levels 1-2 of r.r [+ all-reduce] + beta),
+ * 6 separate dot passes (reference op list, native CRS).  Every event costs ~1 us: never on in a clean timing. */
+void sb_cg_phase_timing(sb_cg* s, int on);
+int sb_cg_phase_ms(sb_cg* s, double ms_out[8], int count_out[8]);
 /* device control block: out = {stop, stop_next, iters, n_rr, n_pAp} (proof that the
  * timed iterations really ran) */
 void sb_cg_counters(const sb_cg* s, int out[5]);

@@ -1073,15 +1073,33 @@ __global__ __launch_bounds__(1024) void cg_vector_phase_k(uint32_t n, double* r,
 // while the other workgroups already have their first loads in flight, then publishes alpha through a flag
 // (agent-scope relaxed atomics, vp_* above) on which the others wait.  The same for the beta step / loop test in
 // front of the p update.  Unlike cg_vector_phase_k nobody waits for ALL workgroups, only for workgroup 0, which is
-// dispatched first: no residency requirement, the reads and writes of the kernel still overlap freely, and the
+// dispatched first: no residency requirement (the launch counter moves when the LAST workgroup leaves, lead_leave), the
+// reads and writes of the kernel still overlap freely, and the
 // ~4 us of a dependent single-workgroup launch become the ~2 us the reduction itself takes.
 // 1024 threads per workgroup, so that workgroup 0 IS the reduction workgroup of the canonical dot.
 // =============================================================================
 struct Lead { // device control of one lead kernel, zeroed once
   unsigned long long flag, valueBits, stop;
   unsigned long long launches; // finished launches: the next one's sequence number - 1
+  unsigned long long done;     // workgroups of the running launch that have read `launches` and left (lead_leave)
   int error;
 };
+
+// Every workgroup reads Ld->launches when it starts, and a grid of more workgroups than the device holds starts in
+// rounds: the counter may therefore only move once EVERY workgroup of the launch has read it.  The last workgroup to
+// leave advances it (round 2 had workgroup 0 do so in the middle of the launch: a workgroup dispatched after that
+// read the new value, waited for a flag nobody would publish and ran into the time-out -- ADVICE r2).
+__device__ __forceinline__ void lead_leave(Lead* Ld, unsigned long long seq)
+{
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long prev = __hip_atomic_fetch_add(&Ld->done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == (unsigned long long)gridDim.x - 1ull) {
+      vp_store(&Ld->done, 0ull);
+      vp_store(&Ld->launches, seq);
+    }
+  }
+}
 
 // workgroup 0: total = the finished dot product.  Everybody returns the published (value, stop); false: timeout
 template <int MODE>
@@ -1097,7 +1115,6 @@ __device__ __forceinline__ bool lead_step(CgScalars* S, const double* __restrict
       vp_store(&Ld->stop, (unsigned long long)S->stop);
       vp_stores_done();
       vp_store(&Ld->flag, seq);
-      Ld->launches = seq;
     }
   }
   if (threadIdx.x == 0) {
@@ -1133,11 +1150,11 @@ __global__ __launch_bounds__(1024) void cg_lead_r_k(uint32_t n, const double* __
     r1 = *reinterpret_cast<const double2*>(r + e1), a1 = *reinterpret_cast<const double2*>(Ap + e1);
   }
   const int stopped            = S->stop;
-  const unsigned long long seq = Ld->launches + 1ull;
-  if (stopped) return;
+  const unsigned long long seq = vp_load(&Ld->launches) + 1ull;
+  if (stopped) return; // (the same decision in every workgroup: nobody counts, the counter stays)
   double alpha;
   int st;
-  if (!lead_step<2>(S, pApPartials, m, rr_hist, pAp_hist, Ld, seq, timeoutTicks, lds16, &shVal, &shFlag, alpha, st)) return;
+  if (!lead_step<2>(S, pApPartials, m, rr_hist, pAp_hist, Ld, seq, timeoutTicks, lds16, &shVal, &shFlag, alpha, st)) return; // (fatal at the host)
   const double nalpha = -alpha;
   bool have = pair0;
   while (have) {
@@ -1174,6 +1191,7 @@ __global__ __launch_bounds__(1024) void cg_lead_r_k(uint32_t n, const double* __
     t = butterfly32(t);
     if ((lane & 31u) == 0) rrPartials[s * 2u + (lane >> 5)] = t;
   }
+  lead_leave(Ld, seq);
 }
 
 // beta step / loop test + p = r + beta p + the x update the previous body owes   (:107-116, :127)
@@ -1197,12 +1215,15 @@ __global__ __launch_bounds__(1024) void cg_lead_p_k(uint32_t n, const double* __
   if (n2) load(min(i, last), a0, b0, x0), load(min(i + stride, last), a1, b1, x1);
   const int stopped            = S->stop;
   const double alpha           = S->alpha; // of the previous body: written by the kernel before this one
-  const unsigned long long seq = Ld->launches + 1ull;
+  const unsigned long long seq = vp_load(&Ld->launches) + 1ull;
   if (stopped) return;
   double beta;
   int st;
   if (!lead_step<1>(S, rrPartials, m, rr_hist, pAp_hist, Ld, seq, timeoutTicks, lds16, &shVal, &shFlag, beta, st)) return;
-  if (st) return; // the loop has ended: p stays, the x update stays owed (cg_x_finalize)
+  if (st) { // the loop has ended: p stays, the x update stays owed (cg_x_finalize)
+    lead_leave(Ld, seq);
+    return;
+  }
   auto finish = [&](uint32_t j, const double2& a, const double2& b, double2 xv) {
     xv.x = xv.x + alpha * b.x;
     xv.y = xv.y + alpha * b.y;
@@ -1224,6 +1245,7 @@ __global__ __launch_bounds__(1024) void cg_lead_p_k(uint32_t n, const double* __
     x[n - 1]        = x[n - 1] + alpha * bb;
     p[n - 1]        = r[n - 1] + beta * bb;
   }
+  lead_leave(Ld, seq);
 }
 
 // =============================================================================

@@ -65,6 +65,9 @@ struct Rccl {
   int (*GroupStart)();
   int (*GroupEnd)();
   const char* (*GetErrorString)(int);
+  int (*CommCount)(ncclComm_t, int*);    // optional (diagnostics only)
+  int (*CommUserRank)(ncclComm_t, int*); // optional
+  int (*CommCuDevice)(ncclComm_t, int*); // optional
 } rccl;
 
 void rccl_open()
@@ -90,6 +93,9 @@ void rccl_open()
   BIND(GroupEnd, "ncclGroupEnd");
   BIND(GetErrorString, "ncclGetErrorString");
 #undef BIND
+  *(void**)(&rccl.CommCount)    = dlsym(rccl.h, "ncclCommCount");
+  *(void**)(&rccl.CommUserRank) = dlsym(rccl.h, "ncclCommUserRank");
+  *(void**)(&rccl.CommCuDevice) = dlsym(rccl.h, "ncclCommCuDevice");
 }
 #define RCCL_CHECK(call)                                                                  \
   do {                                                                                    \
@@ -123,11 +129,14 @@ struct Ctx {
   P2PView* p2pView = nullptr;       // device copy of the view
   unsigned long long p2pSeq = 0;    // exchanges issued so far (identical on every rank)
   bool p2pOn = false;
+  bool p2pUse = true;               // sb_comm_data_plane: 0 = run on the communicator's collectives although the mappings exist
   char p2pReason[256] = "not set up (one rank, or no communicator yet)"; // why the path is on / off
   long long p2pTimeoutTicks = 30000 * P2P_TICKS_PER_MS; // waits inside CG (SB_P2P_TIMEOUT_MS)
 } g;
 
 inline bool multi_rank() { return g.comm != nullptr || g.hasXport; }
+// the peer-mapped data plane is set up AND selected (sb_comm_data_plane)
+inline bool p2p_dots() { return g.p2pOn && g.p2pUse; }
 // a stop flag that is never set, for launches outside a CG loop (kernels that fetch the flag
 // together with other data want a valid address)
 inline const int* zero_flag() { return reinterpret_cast<const int*>(g.scalar + 4); }
@@ -274,6 +283,11 @@ struct sb_cg {
   bool spmvTiming;
   std::vector<hipEvent_t> spmvEv;
   size_t spmvEvUsed;
+  // optional event after every launch of the loop (bench.py's per-kernel breakdown): phase_mark() in sbhip_cg.inc.h
+  bool phaseTiming = false;
+  std::vector<hipEvent_t> phEv;
+  std::vector<int> phId;
+  size_t phUsed = 0;
   int k_next;        // next loop body to enqueue
   bool started;
   CgScalars hostS;   // staging copy for the H2D of the control block

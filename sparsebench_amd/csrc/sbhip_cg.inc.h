@@ -19,6 +19,25 @@ static void mark(sb_cg* s, int region)
   s->evUsed++;
 }
 
+// Per-kernel breakdown of the loop (bench.py): with sb_cg_phase_timing on, an event follows every launch of a loop
+// body; the time between two consecutive events belongs to the phase that ENDS at the second one.  Events serialise
+// nothing the stream does not already serialise, but each costs ~1 us of its own: the clean it/s is never taken with
+// them on.
+enum { PH_P_UPDATE = 0, PH_HALO = 1, PH_SPMV = 2, PH_ALPHA = 3, PH_R_UPDATE = 4, PH_BETA = 5, PH_DOT_PASS = 6, PH_COUNT = 7 };
+static void phase_mark(sb_cg* s, int ph)
+{ // ph = the phase that ends here (-1: start marker)
+  if (!s->phaseTiming) return;
+  if (s->phUsed == s->phEv.size()) {
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreate(&e));
+    s->phEv.push_back(e);
+    s->phId.push_back(-1);
+  }
+  s->phId[s->phUsed] = ph;
+  HIP_CHECK(hipEventRecord(s->phEv[s->phUsed], g.stream));
+  s->phUsed++;
+}
+
 sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host, const double* xexact_host)
 {
   need_init();
@@ -79,6 +98,7 @@ void sb_cg_free(sb_cg* s)
   if (s->iterGraph) HIP_CHECK(hipGraphExecDestroy(s->iterGraph));
   for (hipEvent_t e : s->ev) HIP_CHECK(hipEventDestroy(e));
   for (hipEvent_t e : s->spmvEv) HIP_CHECK(hipEventDestroy(e));
+  for (hipEvent_t e : s->phEv) HIP_CHECK(hipEventDestroy(e));
   HIP_CHECK(hipEventDestroy(s->evLoop0));
   HIP_CHECK(hipEventDestroy(s->evLoop1));
   sb_free(s->r), sb_free(s->Ap), sb_free(s->x), sb_free(s->b), sb_free(s->p), sb_free(s->xexact);
@@ -130,7 +150,7 @@ static bool vphase_plan(sb_cg* s)
   const bool off    = getenv("SB_VPHASE") && atoi(getenv("SB_VPHASE")) == 0;
   const bool shared = getenv("SB_SHARED_GPU") && atoi(getenv("SB_SHARED_GPU")) != 0;
   if (s->fused != 2 || off || s->nr == 0) return false;
-  if (multi_rank() && (!g.p2pOn || shared)) return false;
+  if (multi_rank() && (!p2p_dots() || shared)) return false;
   const uint32_t nSpans = ((s->nr + 255u) >> 8) * 2u;
   if (multi_rank()) return vphase_try<1, true>(s, nSpans) || vphase_try<2, true>(s, nSpans) || vphase_try<4, true>(s, nSpans);
   return vphase_try<1, false>(s, nSpans) || vphase_try<2, false>(s, nSpans) || vphase_try<4, false>(s, nSpans);
@@ -153,16 +173,18 @@ static bool lead_plan(sb_cg* s)
 int sb_cg_launches_per_body(sb_cg* s) { return vphase_plan(s) ? 2 : lead_plan(s) ? 3 : s->fused ? 5 : 0; }
 
 static long long lead_timeout() { return 2000ll * P2P_TICKS_PER_MS; }
-static dim3 lead_grid(uint32_t work, uint32_t perBlock)
-{ // 1024-thread workgroups: at most two per CU
-  const uint32_t cap = (uint32_t)g.prop.multiProcessorCount * 2u;
+template <typename K> static dim3 lead_grid(K kernel, uint32_t work, uint32_t perBlock)
+{ // one round of resident 1024-thread workgroups (what the occupancy calculation says fits: 1 per CU at ~96 VGPRs)
+  int perCU = 0;
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, 1024, 0));
+  const uint32_t cap = (uint32_t)g.prop.multiProcessorCount * (uint32_t)std::max(1, perCU);
   return dim3(std::max(1u, std::min(cap, (work + perBlock - 1) / perBlock)));
 }
 // alpha step + r update + r.r partials (-> partials2)
 static void launch_lead_r(sb_cg* s)
 {
   const uint32_t nSpans = ((s->nr + 255u) >> 8) * 2u;
-  hipLaunchKernelGGL(cg_lead_r_k, lead_grid(nSpans, 32) /* two spans per wave and step */, dim3(1024), 0, g.stream, s->nr, s->Ap,
+  hipLaunchKernelGGL(cg_lead_r_k, lead_grid(cg_lead_r_k, nSpans, 32) /* two spans per wave and step */, dim3(1024), 0, g.stream, s->nr, s->Ap,
       s->r, s->S, s->partials, s->partials2, s->nPartials, s->rr_hist, s->pAp_hist, s->lead + 0, lead_timeout());
   HIP_CHECK(hipGetLastError());
   s->betaOwed = true;
@@ -170,7 +192,7 @@ static void launch_lead_r(sb_cg* s)
 // beta step / loop test + p update + owed x update
 static void launch_lead_p(sb_cg* s)
 {
-  hipLaunchKernelGGL(cg_lead_p_k, lead_grid(s->nr / 2 + 1, 2048) /* two element pairs per thread and step */, dim3(1024), 0,
+  hipLaunchKernelGGL(cg_lead_p_k, lead_grid(cg_lead_p_k, s->nr / 2 + 1, 2048) /* two element pairs per thread and step */, dim3(1024), 0,
       g.stream, s->nr, s->r, s->p, s->x, s->S, s->partials2, s->nPartials, s->rr_hist, s->pAp_hist, s->lead + 1, lead_timeout());
   HIP_CHECK(hipGetLastError());
   s->betaOwed = false;
@@ -180,6 +202,7 @@ static void flush_beta(sb_cg* s)
 {
   if (!s->betaOwed) return;
   scalar_launch<1>(s, 1, s->partials2);
+  phase_mark(s, PH_BETA);
   s->betaOwed = false;
 }
 
@@ -226,6 +249,26 @@ double sb_cg_spmv_ms(sb_cg* s, int* launches)
   return total;
 }
 
+void sb_cg_phase_timing(sb_cg* s, int on)
+{
+  s->phaseTiming = on != 0;
+  s->phUsed      = 0;
+}
+
+int sb_cg_phase_ms(sb_cg* s, double ms_out[8], int count_out[8])
+{ // summed duration and number of occurrences of every phase since sb_cg_phase_timing(s, 1); returns the number of phases
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  for (int i = 0; i < 8; i++) ms_out[i] = 0.0, count_out[i] = 0;
+  for (size_t i = 1; i < s->phUsed; i++) {
+    const int ph = s->phId[i];
+    if (ph < 0) continue; // a start marker: the time in front of it (host gaps between run_iters calls) belongs to nobody
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, s->phEv[i - 1], s->phEv[i]));
+    ms_out[ph] += ms, count_out[ph]++;
+  }
+  return PH_COUNT;
+}
+
 void sb_cg_counters(const sb_cg* s, int out[5])
 { // stop, stop_next, iters, n_rr, n_pAp of the device control block
   HIP_CHECK(hipStreamSynchronize(g.stream));
@@ -246,7 +289,7 @@ static bool spmv_can_fuse_dot(const sb_cg* s)
 template <int MODE> static void scalar_launch(sb_cg* s, int defer_x, const double* q, int l1)
 {
   if (!q) q = s->partials;
-  if (multi_rank() && g.p2pOn) { // local reduce, in-kernel all-reduce and scalar step in ONE launch
+  if (multi_rank() && p2p_dots()) { // local reduce, in-kernel all-reduce and scalar step in ONE launch
     hipLaunchKernelGGL((cg_scalar_p2p_k<MODE>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, q,
         s->S, s->rr_hist, s->pAp_hist, defer_x, (const P2PView*)g.p2pView, ++g.p2pSeq, l1);
     HIP_CHECK(hipGetLastError());
@@ -285,11 +328,14 @@ static void spmv_and_pAp(sb_cg* s, const int* stop)
     launch_spmv(s->A, s->p, s->Ap, s->partials, stop);
     spmv_event(s);
     mark(s, R_SPMVM);
+    phase_mark(s, PH_SPMV);
   } else {
     launch_spmv(s->A, s->p, s->Ap, nullptr, stop);
     spmv_event(s);
     mark(s, R_SPMVM);
+    phase_mark(s, PH_SPMV);
     launch_dot_spans(0, n, s->p, s->Ap, nullptr, nullptr, s->S, s->partials, stop);
+    phase_mark(s, PH_DOT_PASS);
   }
 }
 
@@ -309,19 +355,24 @@ static void loop_body(sb_cg* s, int k)
   if (k == 1) {
     if (n) hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, (double*)nullptr, s->S, 1); // p = r (:109)
     mark(s, R_WAXPBY);
+    phase_mark(s, PH_P_UPDATE);
   } else if (vphase_plan(s)) {
     // p = r + beta p (:114) was taken at the end of the previous body's vector phase
   } else if (s->betaOwed) { // (lead kernels) the previous body's beta step / loop test rides in front of the p update
     launch_lead_p(s);
+    phase_mark(s, PH_P_UPDATE);
   } else {
     if (!s->fused) { // rtrans = r.r ; beta (:111-113)
       launch_dot_spans(0, n, s->r, s->r, nullptr, nullptr, s->S, s->partials, stop);
+      phase_mark(s, PH_DOT_PASS);
       scalar_launch<1>(s, 0, nullptr);
       mark(s, R_DDOT);
+      phase_mark(s, PH_BETA);
     }
     if (n) // p = r + beta p (:114); fused path: also the x update owed by the previous body (:127)
       hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, s->fused ? s->x : (double*)nullptr, s->S, 0);
     mark(s, R_WAXPBY);
+    phase_mark(s, PH_P_UPDATE);
   }
   HIP_CHECK(hipGetLastError());
   // Off by default: a cross-stream event dependency costs ~12 us on this platform (measured with
@@ -347,7 +398,8 @@ static void loop_body(sb_cg* s, int k)
     HIP_CHECK(hipStreamWaitEvent(g.stream, g.evJoin, 0));
     spmv_event(s);
     mark(s, R_SPMVM);
-  } else if (multi_rank() && s->halo && s->halo->p2p && spmv_can_fuse_dot(s) && spmv_uses_patterns(s->A)) {
+    phase_mark(s, PH_SPMV);
+  } else if (multi_rank() && halo_p2p_active(s->halo) && spmv_can_fuse_dot(s) && spmv_uses_patterns(s->A)) {
     // :122-126 over peer-mapped memory with the pull inside the SpMV: the halo-touching tiles (stored
     // last) wait for the neighbours' pushes themselves and read the staging area; interior tiles hide it
     // SB_HALO_PUSH_INSIDE=1: the push rides in the SpMV launch too (its first 16 workgroups) instead of a launch of its
@@ -364,6 +416,7 @@ static void loop_body(sb_cg* s, int k)
       hw.push = h->dPush, hw.nPush = h->totalSend ? 16u : 0u;
     } else halo_exchange(h, s->p, stop, nullptr, true, true);
     mark(s, R_COMM);
+    phase_mark(s, PH_HALO);
     hw.flags = h->stage + 2 * (size_t)h->externalCount;
     hw.ext   = reinterpret_cast<const double*>(h->stage + (h->seq & 1ull) * (size_t)h->externalCount);
     hw.src = h->dSrcRank, hw.nsrc = h->indegree, hw.seq = h->seq, hw.err = h->err;
@@ -372,36 +425,44 @@ static void loop_body(sb_cg* s, int k)
     launch_spmv(s->A, s->p, s->Ap, s->partials, stop, 0, nullptr, &hw);
     spmv_event(s);
     mark(s, R_SPMVM);
+    phase_mark(s, PH_SPMV);
   } else {
     halo_exchange(s->halo, s->p, stop, nullptr, true); // :122
     mark(s, R_COMM);
+    if (multi_rank() && s->halo) phase_mark(s, PH_HALO);
     spmv_event(s);
     spmv_and_pAp(s, stop);
   }
   if (vphase_plan(s)) { // alpha | x, r update + r.r | beta, loop test | the next body's p update: one launch
     launch_vphase(s);
+    phase_mark(s, PH_R_UPDATE);
     return;
   }
   if (lead_plan(s)) { // alpha step in front of the r update; the beta step waits for the next body's p update (or flush_beta)
     launch_lead_r(s);
+    phase_mark(s, PH_R_UPDATE);
     return;
   }
   scalar_launch<2>(s, 0, nullptr);
   mark(s, R_DDOT);
+  phase_mark(s, PH_ALPHA);
   if (s->fused) { // r -= alpha Ap (:128) + next r.r, beta, loop test; x += alpha p (:127) is owed
     // (level-1 values of r.r into partials2: `partials` keeps the layout the p.Ap producers write)
     hipLaunchKernelGGL(cg_update_r_k, dim3(std::max(1u, std::min(capV, (((n + 255u) >> 8) + vb / 64 - 1) / (vb / 64)))), dim3(vb), 0, g.stream, n, s->Ap, s->r, s->S,
         s->partials2, stop);
     HIP_CHECK(hipGetLastError());
     mark(s, R_WAXPBY);
+    phase_mark(s, PH_R_UPDATE);
     scalar_launch<1>(s, 1, s->partials2, 1);
     mark(s, R_DDOT);
+    phase_mark(s, PH_BETA);
   } else if (n) {
     const dim3 gridW(stream_grid(n / 2 + 1, 256)), blockW(256); // (the reference-shaped ops keep their 256-thread workgroups)
     hipLaunchKernelGGL(waxpby_sdev_k, gridW, blockW, 0, g.stream, n, s->x, &s->S->alpha, s->p, s->x, stop);
     hipLaunchKernelGGL(waxpby_sdev_k, gridW, blockW, 0, g.stream, n, s->r, &s->S->neg_alpha, s->Ap, s->r, stop);
     HIP_CHECK(hipGetLastError());
     mark(s, R_WAXPBY);
+    phase_mark(s, PH_R_UPDATE);
   }
 }
 
@@ -418,7 +479,7 @@ static void ensure_hist(sb_cg* s, int cap)
 static void run_body_maybe_graph(sb_cg* s, int k)
 { // k >= 2 bodies are iteration-invariant (k lives in the device control block)
   // (lead kernels: the captured body is the chained one, whose p update carries the previous body's beta step)
-  if (k < 2 || !s->use_graph || multi_rank() || s->timing || s->spmvTiming || (lead_plan(s) && !vphase_plan(s) && !s->betaOwed)) {
+  if (k < 2 || !s->use_graph || multi_rank() || s->timing || s->spmvTiming || s->phaseTiming || (lead_plan(s) && !vphase_plan(s) && !s->betaOwed)) {
     loop_body(s, k);
     return;
   }
@@ -476,6 +537,7 @@ void sb_cg_run_iters(sb_cg* s, int iters)
 {
   need_init();
   if (!s->started) SB_FATAL("sb_cg_run_iters before sb_cg_start");
+  phase_mark(s, -1);
   for (int i = 0; i < iters; i++) run_body_maybe_graph(s, s->k_next++);
   flush_beta(s); // every call leaves the loop state complete (counters, history, stop flag)
 }
@@ -497,8 +559,8 @@ int sb_cg_finish(sb_cg* s)
     HIP_CHECK(hipMemcpy(&vp, s->vphase, sizeof vp, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(ld, s->lead, sizeof ld, hipMemcpyDeviceToHost));
     if (ld[0].error || ld[1].error)
-      SB_FATAL("rank %d: a lead kernel's workgroups timed out waiting for workgroup 0's scalar step (SB_LEAD=0 selects the "
-               "separate launches)", g.rank);
+      SB_FATAL("rank %d: a lead kernel's workgroups timed out waiting for workgroup 0's scalar step (sb_cg_set_fused(s, 1) / "
+               "bench.py --fused 1 selects the separate launches)", g.rank);
     if (vp.error)
       SB_FATAL("rank %d: the one-launch vector phase timed out waiting for its own workgroups: the GPU is shared with other "
                "work (set SB_SHARED_GPU=1 or SB_VPHASE=0 to use the separate launches)", g.rank);

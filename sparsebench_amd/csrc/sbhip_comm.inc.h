@@ -218,6 +218,31 @@ int sb_comm_p2p_open(const unsigned char* all_handles)
 int sb_comm_p2p_enabled(void) { return g.p2pOn ? 1 : 0; }
 const char* sb_comm_p2p_reason(void) { return g.p2pReason; }
 
+// Which data plane the CG loop uses from now on: 1 (default) the peer-mapped paths where their set-up succeeded, 0 the
+// communicator's own collectives (all-reduce, send / recv) although the mappings exist -- what SB_P2P=0 SB_P2P_HALO=0
+// would have given, without tearing anything down, so that one process can time both (bench.py).  Collective by
+// contract: every rank calls it with the same value, between solves (the exchange counters of both paths stay in
+// step on all ranks because every rank switches at the same point of its call sequence).
+void sb_comm_data_plane(int peer_mapped)
+{
+  need_init();
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  g.p2pUse = peer_mapped != 0;
+}
+int sb_comm_data_plane_selected(void) { return g.p2pUse ? 1 : 0; }
+
+// what the RCCL communicator itself reports: out = {ranks in the communicator, this rank's id in it, HIP device it is
+// bound to}; returns 1, or 0 when there is no RCCL communicator (one rank, host transport) or the library lacks the queries
+int sb_comm_rccl_info(int out[3])
+{
+  out[0] = out[1] = out[2] = -1;
+  if (!g.comm || !rccl.CommCount || !rccl.CommUserRank || !rccl.CommCuDevice) return 0;
+  RCCL_CHECK(rccl.CommCount(g.comm, &out[0]));
+  RCCL_CHECK(rccl.CommUserRank(g.comm, &out[1]));
+  RCCL_CHECK(rccl.CommCuDevice(g.comm, &out[2]));
+  return 1;
+}
+
 void sb_comm_finalize(void)
 {
   if (g.init) {
@@ -511,6 +536,15 @@ sb_halo* sb_halo_create(uint32_t nr, int outdegree, const int* destinations, con
       SB_FATAL("halo: elementsToSend[%d]=%d out of range", i, elementsToSend[i]);
     idx[i] = oldToNewPerm ? oldToNewPerm[elementsToSend[i]] : (uint32_t)elementsToSend[i];
   }
+  // TEST HOOK (bench.py's pre-flight gate, tests/test_gpu_bench.py): SB_TEST_CORRUPT_HALO=r makes rank r send the
+  // value of ANOTHER of its rows in its first halo slot -- one wrong value arriving at one neighbour, on whichever data
+  // plane carries the exchange -- to prove that a mis-delivered halo line cannot pass the known-answer checks.
+  if (const char* bad = getenv("SB_TEST_CORRUPT_HALO")) {
+    if (atoi(bad) == g.rank && totalSendCount >= 4) {
+      idx[0] = idx[(size_t)totalSendCount / 2 + 1];
+      fprintf(stderr, "sbhip: rank %d: SB_TEST_CORRUPT_HALO is set: halo slot 0 deliberately carries the wrong row (test hook)\n", g.rank);
+    }
+  }
   h->packIdx = (uint32_t*)upload(idx.data(), idx.size() * sizeof(uint32_t));
   HIP_CHECK(hipMalloc(&h->sendBuf, ((size_t)totalSendCount + 1) * sizeof(double)));
   halo_p2p_setup(h);
@@ -518,6 +552,8 @@ sb_halo* sb_halo_create(uint32_t nr, int outdegree, const int* destinations, con
 }
 
 int sb_halo_p2p_enabled(const sb_halo* h) { return h && h->p2p ? 1 : 0; }
+// set up AND selected (sb_comm_data_plane)
+static inline bool halo_p2p_active(const sb_halo* h) { return h && h->p2p && g.p2pUse; }
 const char* sb_halo_p2p_reason(const sb_halo* h) { return h ? h->p2pReason : "no halo plan (one rank)"; }
 
 void sb_halo_free(sb_halo* h)
@@ -535,7 +571,7 @@ static void halo_exchange(sb_halo* h, double* x, const int* stop, hipStream_t st
 {
   if (!h || g.size == 1) return;
   if (!stream) stream = g.stream;
-  if (h->p2p && inCG) { // push into the neighbours' staging areas, pull the own one into the tail of x
+  if (halo_p2p_active(h) && inCG) { // push into the neighbours' staging areas, pull the own one into the tail of x
     const unsigned long long seq = ++h->seq;
     if (h->totalSend)
       hipLaunchKernelGGL(halo_push_k, dim3(stream_grid(h->totalSend, 256)), dim3(256), 0, stream, h->push, x, seq, stop);

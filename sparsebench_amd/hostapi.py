@@ -251,6 +251,17 @@ class CG:
         ms = self.L.sb_cg_spmv_ms(self.ptr, C.byref(n))
         return ms, n.value
 
+    PHASES = ("p_update", "halo", "spmv", "alpha_step", "r_update", "beta_step", "dot_pass")
+
+    def phase_timing(self, on):
+        self.L.sb_cg_phase_timing(self.ptr, int(on))
+
+    def phase_us(self):
+        """{phase: (mean microseconds per occurrence, occurrences)} since phase_timing(True)"""
+        ms, cnt = (C.c_double * 8)(), (C.c_int * 8)()
+        n = self.L.sb_cg_phase_ms(self.ptr, ms, cnt)
+        return {self.PHASES[i]: (1e3 * ms[i] / cnt[i], cnt[i]) for i in range(n) if cnt[i]}
+
     def loop_ms(self):
         return self.L.sb_cg_loop_ms(self.ptr)
 

@@ -49,9 +49,9 @@ def main():
     for mode in ((5, 3, 2, 1, 0) if fmt == "scs" and Cc == 64 else (5, 3, 0) if fmt == "crs" else (0,)):
         prob.use_packed(mode)  # clamped to what the matrix has
         # 2: the vector phase as one launch (with the in-kernel all-reduce only; the test caps its grid so that the
-        # grids of all ranks on the one GPU are resident together), 3: scalar steps inside their consumers (ditto),
-        # 1: five launches per body, 0: reference op list
-        for fused in (2, 3, 1, 0):
+        # grids of all ranks on the one GPU are resident together), 1: five launches per body, 0: reference op list
+        # (3, scalar steps inside their consumers, is a one-rank mode -- DESIGN 4.4 says why -- and behaves as 1 here)
+        for fused in (2, 1, 0):
             cg = hostapi.CG(prob, fused=fused)
             vphase_seen += cg.vector_phase() > 0
             if os.environ.get("SB_TEST_VERBOSE"):

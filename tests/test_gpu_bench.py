@@ -12,11 +12,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*args, env=None):
+def run_bench(*args, env=None, want_rc=0):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, **(env or {})))
-    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    assert out.returncode == want_rc, (out.returncode, out.stderr.decode()[-3000:])
     lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    if want_rc != 0 and not lines:
+        return None, out.stderr.decode()
     assert len(lines) == 1, lines  # exactly ONE line on stdout
     return json.loads(lines[0]), out.stderr.decode()
 
@@ -37,6 +39,56 @@ def test_two_ranks_as_typed(gpu):
     assert d["config"]["dot_allreduce"] in ("in_kernel_peer_mapped", "host_staged_gloo")
     assert d["config"]["dot_allreduce_reason"] and d["config"]["halo_exchange_reason"]  # which data plane ran, and why
     check_fractions(d)
+    # self-validating: both pre-flight problems, on every data plane that was timed, against closed forms + golden + each other
+    pf = d["preflight"]
+    assert pf["ok"] and all(c["ok"] for c in pf["checks"]) and len(pf["checks"]) in (1, 2)
+    for c in pf["checks"]:
+        assert c["rr0"] == c["rr0_closed_form"] and c["pAp1"] == c["pAp1_closed_form"] and len(set(c["history_sha256_by_rank"])) == 1
+        assert c["golden"] == "hpcg32_x2_scs_C64_sigma256" and c["golden_values_compared"] >= 36  # bit for bit vs the oracle's 2-rank run
+    # self-diagnosing: per-rank step times, per-kernel breakdown, K < 100 => median of repeats, the second data plane
+    assert d["timed_repeats"] == 9 and len(d["ms_per_step_repeats"]) == 9
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and pr["ms_per_step_min"] <= pr["ms_per_step_max"] <= d["ms_per_step"] * 1.0001
+    assert len(pr["device"]) == 2 and len(pr["phases_us"]) == 2
+    for name in ("p_update", "spmv", "alpha_step", "r_update", "beta_step", "halo"):
+        assert d["phases_us"][name] > 0 and d["phases_us_max_over_ranks"][name] >= d["phases_us"][name] * 0.999, name
+    if d["config"]["dot_allreduce"] == "in_kernel_peer_mapped":
+        ro = d["rccl_only"]
+        assert ro["value"] > 0 and ro["dot_allreduce"] == "host_staged_gloo" and len(ro["per_rank_ms_per_step"]) == 2
+        assert ro["launches_per_iteration"] == 5 and ro["phases_us"]["alpha_step"] > 0
+    else:
+        assert "note" in d["rccl_only"]
+
+
+def test_a_wrong_halo_value_fails_the_preflight_and_nothing_is_timed(gpu):
+    """SB_TEST_CORRUPT_HALO=1: rank 1 sends another row's value in its first halo slot (library test hook).  The
+    closed-form p.Ap of the first body and the golden history must catch it: exit code 4, no rate in the line."""
+    d, err = run_bench("--gpus", "2", "--transport", "host", "--steps", "10", "--n", "32", "--no-cpu",
+                       env={"SB_TEST_CORRUPT_HALO": "1"}, want_rc=4)
+    assert "PRE-FLIGHT FAILED" in err and "SB_TEST_CORRUPT_HALO" in err
+    assert d is not None and d["value"] is None and d["preflight"]["ok"] is False
+    assert any("p.Ap of the first body" in p for p in d["preflight"]["problems"])
+    assert any("golden" in p for p in d["preflight"]["problems"])
+    # ... at a size without a committed golden the closed form alone must fire (and does on both bricks' sizes)
+    d, err = run_bench("--gpus", "3", "--transport", "host", "--steps", "10", "--n", "16", "--no-cpu",
+                       env={"SB_TEST_CORRUPT_HALO": "2"}, want_rc=4)
+    assert d["value"] is None and any("closed form" in p for p in d["preflight"]["problems"])
+
+
+def test_a_rank_that_dies_ends_the_run_at_once_with_its_exit_code(gpu):
+    """the parent polls ALL its children; one dead rank must not leave the others in a collective for ever"""
+    import time
+    t0 = time.time()
+    d, err = run_bench("--gpus", "3", "--transport", "host", "--steps", "10", "--n", "16", "--no-cpu",
+                       env={"SB_BENCH_TEST_DIE_RANK": "2"}, want_rc=7)
+    assert d is None and "rank 2 exited with code 7" in err and time.time() - t0 < 120
+
+
+def test_six_ranks_the_pools_limit(gpu):
+    d, _ = run_bench("--gpus", "6", "--transport", "host", "--steps", "6", "--warmup", "2", "--n", "32", "--no-cpu")
+    assert d["n_gpus"] == 6 and d["value"] > 0 and d["preflight"]["ok"]
+    assert all(c["golden"] == "hpcg32_x6_scs_C64_sigma256" for c in d["preflight"]["checks"])
+    assert len(d["per_rank"]["ms_per_step"]) == 6 and len(d["config"]["spmv_kernel_mode_by_rank"]) == 6
 
 
 @pytest.mark.parametrize("n_ranks,p2p", [(4, "1"), (4, "0"), (3, "1")])
@@ -45,8 +97,10 @@ def test_more_ranks_and_both_data_planes(gpu, n_ranks, p2p):
                      env={"SB_P2P": p2p, "SB_P2P_HALO": p2p})
     assert d["n_gpus"] == n_ranks and d["value"] > 0
     assert len(d["config"]["spmv_kernel_mode_by_rank"]) == n_ranks  # which SpMV kernel every rank's brick got
+    assert d["preflight"]["ok"]
     if p2p == "0":
         assert d["config"]["dot_allreduce"] == "host_staged_gloo" and "SB_P2P=0" in d["config"]["dot_allreduce_reason"]
+        assert "IS the communicator's data plane" in d["rccl_only"]["note"]
 
 
 def test_single_gpu_line_has_the_contract_keys(gpu):
@@ -60,8 +114,12 @@ def test_single_gpu_line_has_the_contract_keys(gpu):
     assert r["launches_timed"] == 40 and r["bytes_per_launch"] <= r["algorithmic_bytes_per_launch"] * 1.02
     assert abs(d["algorithmic_speedup"] - r["algorithmic_bytes_per_launch"] / r["bytes_per_launch"]) < 1e-9
     if r["kernel"] != "spmv_scs64":
-        assert d["roofline_reference_layout"]["kernel"] == "spmv_scs64"
-        assert d["roofline_reference_layout"]["bytes_per_launch"] == r["algorithmic_bytes_per_launch"]
+        rl = d["roofline_reference_layout"]
+        assert rl["kernel"] == "spmv_scs64" and rl["bytes_per_launch"] == r["algorithmic_bytes_per_launch"]
+        # the section-8d-valid path has a CLEAN rate of its own in the line, slower than the structure-exploiting default
+        assert 0 < rl["cg_iterations_per_s"] < d["value"] and rl["cg_iterations_per_s"] >= rl["cg_iterations_per_s_with_events"] * 0.9
+        assert rl["phases_us"]["spmv"] > d["phases_us"]["spmv"]
+    assert d["preflight"]["ok"] and d["timed_repeats"] == 9 and abs(sum(d["phases_us"].values()) - 1e3 * d["ms_per_step"]) < 0.5e3 * d["ms_per_step"]
     cb = d["cpu_baseline"]
     assert cb and cb["value"] > 0 and cb["cores"] >= 1 and cb["nproc"] >= cb["cores"] and cb["kind"] in ("reference", "port")
     check_fractions(d)
