@@ -160,6 +160,20 @@ def _exact(name):
     return f(e["rr"]), f(e["pAp"]), e
 
 
+def _tree(key):
+    """oracle history in the GPU's own dot order (tests/golden/cg_hist_tree.json, made by make_golden_tree.py): bit-for-bit target"""
+    from conftest import load_json
+    t = load_json("cg_hist_tree.json")[key]
+    return f(t["rr"]), f(t["pAp"]), t
+
+
+def _assert_bits(r, key):
+    rr, pap, t = _tree(key)
+    m, q = min(len(rr), len(r["rr"])), min(len(pap), len(r["pAp"]))
+    assert m >= t["itermax"] - 2 or m == len(r["rr"])
+    assert np.array_equal(r["rr"][:m], rr[:m]) and np.array_equal(r["pAp"][:q], pap[:q]), key
+
+
 def test_history_64_against_exact_dots_and_reference(gpu, golden_1rank):
     """BASELINE configs[1] size.  tests/golden/cg_hist_exact.json = CG with every dot exactly rounded (Dot2,
     CPU, tests/golden/make_golden_exact.py).  The GPU stays within north_star's 1e-12 of it at every live
@@ -169,6 +183,7 @@ def test_history_64_against_exact_dots_and_reference(gpu, golden_1rank):
     ref_rr = f(gd["rr"])
     ex_rr, ex_pap, ex = _exact("hpcg64")
     r = run_gpu("generate", 64, "scs", 64, 1, gd["itermax"])
+    _assert_bits(r, "hpcg64_x1_scs_C64_sigma1")  # bit for bit against the oracle (tree order) at configs[1]'s size
     live = ex_rr / ex_rr[0] >= 1e-20
     d_gpu = _rel(r["rr"], ex_rr)[live].max()
     d_ref = _rel(ref_rr, ex_rr)[live].max()
@@ -188,6 +203,7 @@ def test_full_size_properties_128(gpu, golden_1rank):
     a = run_gpu("generate", n, "scs", 64, 1, 60)
     m = n - 2
     assert a["rr"][0] == m ** 3 + 600 * m ** 2 + 3072 * m + 3200
+    _assert_bits(a, "hpcg128_x1_scs_C64_sigma1")  # bit for bit against the oracle (tree order) at the benchmark size
     c = run_gpu("generate", n, "crs", 64, 1, 60, pack_mode=0)  # native CRS kernel
     assert np.array_equal(a["rr"], c["rr"]) and np.array_equal(a["pAp"], c["pAp"])
     c3 = run_gpu("generate", n, "crs", 64, 1, 60, pack_mode=3)  # CRS through its pattern mirror (the default here)
@@ -195,6 +211,8 @@ def test_full_size_properties_128(gpu, golden_1rank):
     u = run_gpu("generate", n, "scs", 64, 1, 60, fused=False)
     assert np.array_equal(a["rr"], u["rr"]) and np.array_equal(a["x"], u["x"])
     s = run_gpu("generate", n, "scs", 64, 256, 60)
+    _assert_bits(s, "hpcg128_x1_scs_C64_sigma256")  # ... configs[2] itself, default kernel
+    _assert_bits(c, "hpcg128_x1_crs")
     # the benchmark configuration: every SpMV kernel (reference layout, compressed stream, LDS window,
     # pattern dictionary + row patterns = the default) gives the same bits at full size
     for mode in (0, 1, 2, 3):

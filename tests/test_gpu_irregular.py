@@ -38,6 +38,12 @@ def test_small_spmv_and_cg_bit_equal_to_oracle(gpu, fmt, sigma):
     x = rng.standard_normal(g.nc)
     yref = g.spmv(x)
     o = po.cg(g, itermax=40, fmt=fmt, Cc=64, sigma=sigma, dot="tree", want_x=True)
+    # the REFERENCE's own history on this matrix (tests/golden/cg_hist_irregular_ref.json, captured from the reference's
+    # reader + solveCG on the stand-in exported as .mtx): north_star's 1e-12 holds against the reference itself here
+    import json
+    import os
+    e = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cg_hist_irregular_ref.json")))["irregular%d" % n]
+    ref_rr, ref_pap = np.array([float(v) for v in e["rr"]]), np.array([float(v) for v in e["pAp"]])
     prob = hostapi.Problem("irregular", n, n, n, fmt=fmt, Cc=64, sigma=sigma)
     default = prob.pack_info()["mode"]
     modes = sorted({default, prob.use_packed(0), prob.use_packed(1)})
@@ -51,6 +57,7 @@ def test_small_spmv_and_cg_bit_equal_to_oracle(gpu, fmt, sigma):
             assert k == o["k"] == 40
             assert np.array_equal(rr, o["rr"]) and np.array_equal(pap, o["pAp"]), (fmt, sigma, mode, fused)
             assert np.array_equal(cg.solution(), o["x"][0])
+            assert (np.abs(rr - ref_rr) / ref_rr).max() <= 1e-12 and (np.abs(pap - ref_pap) / ref_pap).max() <= 1e-12
             cg.free()
     prob.free()
 

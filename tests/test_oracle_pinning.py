@@ -201,3 +201,57 @@ def test_cg_tolerance_story_against_exactly_rounded_dots(n, its, golden_1rank):
     if its == ex["itermax"]:  # the numbers quoted in DESIGN.md
         assert abs(d_ref - ex["reference_dev"]["rel"]) <= 1e-3 * d_ref and abs(d_tree - ex["tree_dev"]["rel"]) <= 1e-3 * d_tree
     g.free()
+
+
+# ---- the irregular-nnz input class (BASELINE configs[4]'s stand-in) pinned on the reference itself -------------------
+def _irregular_oracle_matrix(n):
+    import hashlib
+    from sparsebench_amd import hostapi
+    p = hostapi.Problem("irregular", n, n, n, fmt="crs", upload=False)
+    rp = p.array("rowPtr").copy()
+    col, val = p.gm_entries()
+    g = po.GMatrix.from_csr(rp, col, val, nc=p.nc)
+    p.free()
+    h = hashlib.sha256()
+    for a in (rp.astype(np.uint32), col.astype(np.uint32), val.astype(np.float64)):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return g, h.hexdigest()
+
+
+@pytest.mark.parametrize("n", [12, 24])
+def test_irregular_stand_in_history_bit_identical_to_the_reference(n):
+    """tests/golden/cg_hist_irregular_ref.json: the reference's own reader + convertMatrix + solveCG run on the stand-in
+    exported as .mtx (make_golden_irregular_ref.py; the reference built exactly the generator's CRS arrays from the
+    file -- fingerprint below).  The oracle with the reference's sequential dot reproduces every r.r / p.Ap bit for
+    bit: the oracle is pinned on long rows, far couplings and 2 M distinct values too, not only on stencils.  And the
+    GPU's dot order (oracle dot='tree', bit-identical to the HIP path by tests/test_gpu_irregular.py) stays within
+    north_star's 1e-12 of the REFERENCE ITSELF on this input (observed 2e-14 / 9e-14)."""
+    e = load_json("cg_hist_irregular_ref.json")["irregular%d" % n]
+    rr = np.array([float(v) for v in e["rr"]])
+    pap = np.array([float(v) for v in e["pAp"]])
+    g, sha = _irregular_oracle_matrix(n)
+    assert sha == e["matrix_sha256"] and g.nr == e["rows"] and g.nnzTrue == e["nnz"]
+    o = po.cg(g, itermax=e["itermax"], dot="seq")
+    assert o["k"] == e["k"] and np.array_equal(o["rr"], rr) and np.array_equal(o["pAp"], pap)
+    t = po.cg(g, itermax=e["itermax"], dot="tree")
+    assert (np.abs(t["rr"] - rr) / rr).max() <= 1e-12 and (np.abs(t["pAp"] - pap) / pap).max() <= 1e-12
+    g.free()
+
+
+@pytest.mark.skipif(not po.ref_available("crs"), reason="oracle/_ref not built (no /root/reference here)")
+def test_live_reference_on_the_irregular_stand_in(tmp_path):
+    """the same link live: export 12^3 as .mtx now, let the reference read and solve it, compare with the committed history"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(os.path.dirname(REFDATA), "make_golden_irregular_ref.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    nr, nc, rp, col, val = mk.stand_in(12)
+    path = str(tmp_path / "irregular_12.mtx")
+    mk.write_mtx(path, nr, rp, col, val)
+    ref = po.Ref("crs")
+    ref.setup(path)
+    rrp, rcol, rval = ref.csr()
+    assert np.array_equal(rrp, rp) and np.array_equal(rcol, col) and np.array_equal(rval, val)
+    h = ref.solve_cg(40)
+    e = load_json("cg_hist_irregular_ref.json")["irregular12"]
+    assert np.array_equal(h["rr"], np.array([float(v) for v in e["rr"]])) and h["k"] == e["k"]
