@@ -646,12 +646,29 @@ def run_rank(args):
             cg_tmp = hostapi.CG(prob, fused=args.fused)
             launches, vphase = cg_tmp.launches_per_body(), cg_tmp.vector_phase()
             cg_tmp.free()
+        # third leg, peer-mapped halo only: the halo push inside the SpMV launch (one launch fewer per body).  Which
+        # variant is faster can only be decided with one rank per GPU, i.e. by this very run on a real node; validated by
+        # its own pre-flight, and a failure here does not invalidate `value` (the variant is simply reported as failed).
+        res_inside, inside_checks, inside_problems = None, [], []
+        if world > 1 and p2p_halo and default >= 3 and not args.no_push_inside_leg:
+            L.sb_comm_halo_push_inside(1)
+            if not args.no_preflight:
+                inside_checks, inside_problems = preflight("peer-mapped data plane, push inside the SpMV launch", prob)
+            if not inside_problems:
+                res_inside = measure(prob, [default])
+                launches_inside = launches
+            L.sb_comm_halo_push_inside(0)
+            cg_tmp = hostapi.CG(prob, fused=args.fused)
+            launches, vphase = cg_tmp.launches_per_body(), cg_tmp.vector_phase()
+            cg_tmp.free()
         rccl = (ctypes.c_int * 3)()
         has_rccl = L.sb_comm_rccl_info(rccl) if world > 1 else 0
         per_rank = gather({"rank": rank, "device": device, "spmv_mode": default, "ms_per_step": 1e3 * res[default]["t_mine"] / K,
                            "rccl": list(rccl) if has_rccl else None, "phases_us": phase_table(res[default]["phases"]),
                            "ms_per_step_rccl_only": (1e3 * res_coll[default]["t_mine"] / K) if res_coll else None,
-                           "phases_us_rccl_only": phase_table(res_coll[default]["phases"]) if res_coll else None})
+                           "phases_us_rccl_only": phase_table(res_coll[default]["phases"]) if res_coll else None,
+                           "ms_per_step_push_inside": (1e3 * res_inside[default]["t_mine"] / K) if res_inside else None,
+                           "phases_us_push_inside": phase_table(res_inside[default]["phases"]) if res_inside else None})
         if rank == 0:
             d = res[default]
             it_s = K / d["t_clean"]
@@ -740,7 +757,20 @@ def run_rank(args):
                     "phases_us_by_rank": [r["phases_us_rccl_only"] for r in per_rank],
                     "note": "same bricks, same K steps, peer-mapped paths switched off (sb_comm_data_plane(0)): the communicator's "
                             "all-reduce and send/recv carry the dots and the halo"}
-            elif world > 1:
+            if res_inside:
+                c = res_inside[default]
+                out["push_inside"] = {
+                    "value": world * K / c["t_clean"], "ms_per_step": 1e3 * c["t_clean"] / K,
+                    "ms_per_step_repeats": [1e3 * t / K for t in c["t_repeats"]], "launches_per_iteration": launches_inside,
+                    "per_rank_ms_per_step": [r["ms_per_step_push_inside"] for r in per_rank], "phases_us": phase_table(c["phases"]),
+                    "phases_us_by_rank": [r["phases_us_push_inside"] for r in per_rank],
+                    "preflight": {"ok": True, "checks": inside_checks},
+                    "note": "the same K steps with the rank's halo push carried by the first workgroups of the SpMV launch "
+                            "(sb_comm_halo_push_inside(1)) instead of a push launch of its own; not the default -- ranks sharing a "
+                            "GPU (rehearsals) keep each other's pushes off the CUs, so only a run with one rank per GPU can rank the two"}
+            elif inside_problems:
+                out["push_inside"] = {"value": None, "preflight": {"ok": False, "problems": inside_problems, "checks": inside_checks}}
+            if res_coll is None and world > 1:
                 out["rccl_only"] = {"note": "not timed separately: " + (
                     "--no-rccl-leg" if args.no_rccl_leg else "the peer-mapped paths are off, `value` IS the communicator's data plane")}
         prob.free()
@@ -821,6 +851,7 @@ def main():
     ap.add_argument("--all-clean", action="store_true", help="N > 1: also time the reference-layout kernel without events "
                                                              "(N = 1 always does)")
     ap.add_argument("--no-rccl-leg", action="store_true", help="N > 1: do not time the second data plane (rccl_only)")
+    ap.add_argument("--no-push-inside-leg", action="store_true", help="N > 1: do not time the push-inside-the-SpMV variant")
     ap.add_argument("--no-preflight", action="store_true", help="skip the known-answer checks (lab use; the line says so)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=60)

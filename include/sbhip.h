@@ -89,7 +89,9 @@ double sb_matrix_spmv_bytes(const sb_matrix* m);
  * Stays in force until replaced (n = 0 clears); uploads whose nc - nr differs from n ignore it. */
 void sb_set_external_ids(const uint32_t* global_ids, uint32_t n);
 int sb_matrix_pack_level(const sb_matrix* m);
-/* select the SpMV kernel at run time: 0 reference-layout stream, 1 packed stream with x
+/* select the SpMV kernel at run time.  The product has two: 0 the reference-layout stream, 5 the masked row programs
+ * (level 6) where the matrix has them (the default then); any other request falls to the next lower of the two.
+ * Lab builds (sb_lab_build) also run the intermediate levels as kernels of their own: 1 packed stream with x
  * gathered through the cache, 2 packed stream with each workgroup's x window staged in LDS
  * (built when every tile's window fits; SB_PACK=2 stops at mode 1), 3 one-byte pattern
  * codes naming (value, window-slot delta) pairs + LDS window (built when every tile has
@@ -188,6 +190,10 @@ const char* sb_comm_p2p_reason(void);
  * after the switch. */
 void sb_comm_data_plane(int peer_mapped);
 int sb_comm_data_plane_selected(void);
+/* Variant of the peer-mapped halo exchange: 1 = the halo push rides in the SpMV launch (its first workgroups send
+ * p[elementsToSend], src/comm.c:635-638) instead of a launch of its own; 0 = separate push kernel (default;
+ * SB_HALO_PUSH_INSIDE=1 changes the default).  Same bits.  Collective, between solves. */
+void sb_comm_halo_push_inside(int on);
 /* what the RCCL communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice):
  * out = {ranks, this rank, HIP device}; returns 0 (out = -1) without an RCCL communicator */
 int sb_comm_rccl_info(int out[3]);
@@ -286,6 +292,11 @@ void sb_cg_counters(const sb_cg* s, int out[5]);
 double sb_debug_stream_read_gbs(size_t bytes, int reps);
 
 const char* sb_version(void);
+/* 1: a lab build (-DSB_LAB, `make lab`): the product plus the alternatives that were measured slower and are kept for
+ * the record -- compressed-mirror levels 1-5 as SpMV kernels of their own (sb_matrix_use_packed 1-3),
+ * sb_cg_set_fused 2 / 3, sb_cg_set_graph, SB_HALO_OVERLAP.  0: the product, in which those requests fall back to
+ * what ships (modes 0 / 5, fused 0 / 1, no graph). */
+int sb_lab_build(void);
 
 #ifdef __cplusplus
 }

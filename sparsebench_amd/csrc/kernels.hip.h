@@ -893,6 +893,8 @@ struct VPhase { // device control block, zeroed once
   int error;
 };
 
+#ifdef SB_LAB // the one-launch vector phase and the lead kernels: measured slower than the five launches; lab builds only
+
 __device__ __forceinline__ unsigned long long vp_load(const unsigned long long* p)
 {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1064,6 +1066,8 @@ __global__ __launch_bounds__(1024) void cg_vector_phase_k(uint32_t n, double* r,
   }
 }
 
+#endif // SB_LAB (vector phase)
+
 // =============================================================================
 // Scalar steps inside their consumers ("lead" kernels): 5 -> 3 launches per CG body.
 // (One rank only: with several ranks the combination with the in-kernel all-reduce and the in-SpMV halo wait timed out
@@ -1084,6 +1088,8 @@ struct Lead { // device control of one lead kernel, zeroed once
   unsigned long long done;     // workgroups of the running launch that have read `launches` and left (lead_leave)
   int error;
 };
+
+#ifdef SB_LAB
 
 // Every workgroup reads Ld->launches when it starts, and a grid of more workgroups than the device holds starts in
 // rounds: the counter may therefore only move once EVERY workgroup of the launch has read it.  The last workgroup to
@@ -1247,6 +1253,8 @@ __global__ __launch_bounds__(1024) void cg_lead_p_k(uint32_t n, const double* __
   }
   lead_leave(Ld, seq);
 }
+
+#endif // SB_LAB (lead kernels)
 
 // =============================================================================
 // permutation / halo helpers

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void pack_write_k(const uint32_t* __restrict__
 // (eight columns) are kept in flight.  (Deeper batching / prefetching variants were
 // measured slower: they cost occupancy, and the limiter is the gather instruction rate
 // of the vector cache, not the length of the dependency chain.)
+#ifdef SB_LAB // levels 1-2 as a kernel of their own: lab builds only (the BUILD of these levels feeds level 6 and stays)
 template <bool DICT, bool DOT>
 __global__ __launch_bounds__(256) void spmv_scs64_packed(const PackMeta* __restrict__ meta,
     const uint32_t* __restrict__ idx, const uint32_t* __restrict__ codes,
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_packed(const PackMeta* __restr
   }
   if (active) spmv_epilogue<DOT>(chunk, lane, acc, x, y, nr, dotPartials);
 }
+#endif // SB_LAB
 
 // ---- level 3: the x window of a tile staged in LDS -------------------------------------
 // With 3 bytes per element the kernel is no longer HBM-bound; PMC shows the vector
@@ -262,6 +264,7 @@ __global__ __launch_bounds__(256) void pack_slots_k(const uint32_t* __restrict__
   }
 }
 
+#ifdef SB_LAB // level 3 as a kernel of its own: lab builds only
 template <bool DICT, bool DOT>
 __global__ __launch_bounds__(256) void spmv_scs64_lds(const PackMeta* __restrict__ meta,
     const uint32_t* __restrict__ slots, const uint32_t* __restrict__ codes,
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(256) void spmv_scs64_lds(const PackMeta* __restrict
   }
   spmv_epilogue<DOT>(chunk, lane, acc, x, y, nr, dotPartials);
 }
+#endif // SB_LAB
 
 // ---- level 4: pattern dictionary ---------------------------------------------------------
 // In the LDS-window kernel an element costs 3 B (value code + 16-bit slot).  In a matrix
@@ -732,6 +736,14 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
     const u32x2 h2  = *(lane < (uint32_t)PAT_STOP_LANE ? hp + lane : reinterpret_cast<const u32x2*>(stop));
     hvx = h2.x, hvy = h2.y;
   }
+  // (level 6, mapped windows) the slot map is stored in HEADER order, so its address does not wait for the header: the
+  // map travels in round trip 1 next to it, and x -- which needs both -- in round trip 2 (round 2 had header -> map -> x)
+  uint32_t dmap[WB];
+  if (MASKED && slotMap) {
+    const uint16_t* mp = slotMap + (size_t)hidx * mapStride + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < WB; k++) dmap[k] = mp[min((uint32_t)k * 256u, mapStride - 256u)];
+  }
   auto field = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)hvx, i); };
   // per-chunk field of the wave's c-th chunk (chunk wv + 4 c of the tile): half X for c = 0, half Y for c = 1
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -798,13 +810,9 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
   const double xpad = x[padCol]; // slot 0: what padding multiplies (src/matrix-SCS.c:151-155)
   double t[WB];
   const bool mappedWin = MASKED && (flags & PAT_MAPPED_WINDOW) != 0u; // uniform per workgroup
-  if (mappedWin) { // slot by slot through the map (its address depends on the tile number only: same round trip as the header)
-    const uint16_t* mp = slotMap + (size_t)tile * mapStride + threadIdx.x;
-    uint32_t d[WB];
+  if (mappedWin) { // slot by slot through the map (fetched next to the header, above)
 #pragma unroll
-    for (int k = 0; k < WB; k++) d[k] = mp[min((uint32_t)k * 256u, mapStride - 256u)];
-#pragma unroll
-    for (int k = 0; k < WB; k++) t[k] = xcol(field(12 + min(k, 17)) + d[k]);
+    for (int k = 0; k < WB; k++) t[k] = xcol(field(12 + min(k, 17)) + dmap[k]);
   } else if (simple) { // segment by segment: entry i of segment s -> slot first_s + i
 #pragma unroll
     for (int sI = 0; sI < 3; sI++) {

@@ -129,6 +129,7 @@ struct Ctx {
   P2PView* p2pView = nullptr;       // device copy of the view
   unsigned long long p2pSeq = 0;    // exchanges issued so far (identical on every rank)
   bool p2pOn = false;
+  bool pushInside = false;          // sb_comm_halo_push_inside (initialised from SB_HALO_PUSH_INSIDE at sb_init)
   bool p2pUse = true;               // sb_comm_data_plane: 0 = run on the communicator's collectives although the mappings exist
   char p2pReason[256] = "not set up (one rank, or no communicator yet)"; // why the path is on / off
   long long p2pTimeoutTicks = 30000 * P2P_TICKS_PER_MS; // waits inside CG (SB_P2P_TIMEOUT_MS)
@@ -227,6 +228,7 @@ struct sb_matrix {
   TileSeg* mSegs       = nullptr; // (mOwnsTables) when the windows are laid out in original column order
   uint16_t* mSlotMap   = nullptr; // ... then: [tile][mMapStride] slot -> device column - the 256-slot block's base
   uint32_t mWindow = 0, mMapStride = 0;
+  std::vector<uint32_t> mTileOfHdr; // (build time only) which tile the i-th stored header describes
   uint32_t mCPT = 4, mNTiles = 0, mInterior = 0; // its own tile shape (level 5 may have had to take the smaller one)
   bool mOwnsTables = false;
   double mBytes  = 0.0;
@@ -308,7 +310,13 @@ struct sb_cg {
 // Every sb_* function below is declared extern "C" by include/sbhip.h, which fixes
 // its linkage; the helpers in between stay C++.
 
-const char* sb_version(void) { return "sparsebench_amd sbhip 0.3 (gfx950)"; }
+#ifdef SB_LAB
+const char* sb_version(void) { return "sparsebench_amd sbhip 0.4 (gfx950, LAB build)"; }
+int sb_lab_build(void) { return 1; }
+#else
+const char* sb_version(void) { return "sparsebench_amd sbhip 0.4 (gfx950)"; }
+int sb_lab_build(void) { return 0; }
+#endif
 
 int sb_device_count(void)
 {
@@ -339,6 +347,7 @@ void sb_init(int device)
   HIP_CHECK(hipMemset(g.scalar, 0, 64)); // [0] scratch double, [4] a permanent int 0 (zero_flag)
   g.device = device;
   g.init   = true;
+  g.pushInside = getenv("SB_HALO_PUSH_INSIDE") && atoi(getenv("SB_HALO_PUSH_INSIDE")) != 0;
 }
 
 void sb_finalize(void)

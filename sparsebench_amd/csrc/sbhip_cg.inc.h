@@ -70,10 +70,12 @@ sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host, con
   s->rr_hist = s->pAp_hist = nullptr;
   s->partials2 = (double*)sb_malloc((4 * (size_t)s->nPartials + 4) * sizeof(double));
   HIP_CHECK(hipMemsetAsync(s->partials2, 0, (4 * (size_t)s->nPartials + 4) * sizeof(double), g.stream));
+#ifdef SB_LAB
   s->lead = (Lead*)sb_malloc(2 * sizeof(Lead));
   HIP_CHECK(hipMemsetAsync(s->lead, 0, 2 * sizeof(Lead), g.stream));
   s->vphase = (VPhase*)sb_malloc(sizeof(VPhase));
   HIP_CHECK(hipMemsetAsync(s->vphase, 0, sizeof(VPhase), g.stream));
+#endif
   s->fused      = 1;
   s->use_graph  = 0;
   s->graphReady = false;
@@ -113,12 +115,18 @@ static void drop_graph(sb_cg* s)
 }
 
 void sb_cg_set_fused(sb_cg* s, int fused)
-{ // 0: the reference's op list; 1 (default): dots fused into their producers (5 launches per body); 2: + the vector
-  // phase of a body as one launch where that is possible (2 launches per body); 3: + the two scalar steps taken by
-  // workgroup 0 of their consumers (3 launches per body).  2 and 3 were measured SLOWER at 128^3, see below.
+{ // 0: the reference's op list; 1 (default): dots fused into their producers (5 launches per body).  Lab builds (-DSB_LAB)
+  // additionally: 2: the vector phase of a body as one launch where that is possible (2 launches per body); 3: the two
+  // scalar steps taken by workgroup 0 of their consumers (3 launches per body) -- both measured SLOWER at 128^3, see
+  // below; the product treats every non-zero level as 1.
+#ifndef SB_LAB
+  fused = fused ? 1 : 0;
+#endif
   if (s->fused != fused) drop_graph(s), s->vSP = -1, s->leadPlan = -1;
   s->fused = fused;
 }
+
+#ifdef SB_LAB
 
 // Measured (MI355X, HPCG 128^3, Sell-64-256): 61.1 us per iteration against 51.5 us with the five launches.  The four
 // kernels it replaces overlap their reads and writes freely (134 MB in ~20 us, Infinity-Cache assisted) and pay ~8 us
@@ -155,9 +163,14 @@ static bool vphase_plan(sb_cg* s)
   if (multi_rank()) return vphase_try<1, true>(s, nSpans) || vphase_try<2, true>(s, nSpans) || vphase_try<4, true>(s, nSpans);
   return vphase_try<1, false>(s, nSpans) || vphase_try<2, false>(s, nSpans) || vphase_try<4, false>(s, nSpans);
 }
+#else  // the product: five launches per body (or the reference's op list); DESIGN 4.4 has the measurements of the rest
+static bool vphase_plan(sb_cg*) { return false; }
+#endif // SB_LAB
 int sb_cg_vector_phase(sb_cg* s) { return vphase_plan(s) ? s->vSP : 0; }
 
 template <int MODE> static void scalar_launch(sb_cg* s, int defer_x, const double* q, int l1 = 0);
+
+#ifdef SB_LAB
 
 // The scalar steps inside their consumers (sb_cg_set_fused(s, 3)): one rank only.
 // Measured (MI355X, HPCG 128^3, Sell-64-256, same box, back to back): 58.6 us per iteration against 51.7 us with the
@@ -170,7 +183,12 @@ static bool lead_plan(sb_cg* s)
   s->leadPlan = (s->fused == 3 && s->nr > 0 && !multi_rank()) ? 1 : 0;
   return s->leadPlan > 0;
 }
+#else
+static bool lead_plan(sb_cg*) { return false; }
+#endif // SB_LAB
 int sb_cg_launches_per_body(sb_cg* s) { return vphase_plan(s) ? 2 : lead_plan(s) ? 3 : s->fused ? 5 : 0; }
+
+#ifdef SB_LAB
 
 static long long lead_timeout() { return 2000ll * P2P_TICKS_PER_MS; }
 template <typename K> static dim3 lead_grid(K kernel, uint32_t work, uint32_t perBlock)
@@ -226,7 +244,22 @@ static void launch_vphase(sb_cg* s)
 #undef VP_LAUNCH
   HIP_CHECK(hipGetLastError());
 }
-void sb_cg_set_graph(sb_cg* s, int use_graph) { s->use_graph = use_graph; }
+#else
+static void launch_lead_r(sb_cg*) {}
+static void launch_lead_p(sb_cg*) {}
+static void flush_beta(sb_cg*) {}
+static void launch_vphase(sb_cg*) {}
+#endif // SB_LAB
+// hipGraph replay of a loop body was measured slower (-7 % at 128^3, -13 ... -35 % at 64^3: DESIGN 4.4): lab builds only
+void sb_cg_set_graph(sb_cg* s, int use_graph)
+{
+#ifdef SB_LAB
+  s->use_graph = use_graph;
+#else
+  (void)use_graph;
+  s->use_graph = 0;
+#endif
+}
 
 void sb_cg_spmv_timing(sb_cg* s, int on)
 {
@@ -378,7 +411,11 @@ static void loop_body(sb_cg* s, int k)
   // Off by default: a cross-stream event dependency costs ~12 us on this platform (measured with
   // an x update moved beside the beta step: 63 -> 88 us per iteration for one fork + join), which
   // is about what the overlap can hide.  SB_HALO_OVERLAP=1 enables it.
+#ifdef SB_LAB
   static const bool overlapHalo = getenv("SB_HALO_OVERLAP") && atoi(getenv("SB_HALO_OVERLAP")) != 0;
+#else
+  const bool overlapHalo = false; // (measured: one cross-stream dependency costs what the overlap hides; lab builds only)
+#endif
   if (overlapHalo && multi_rank() && s->halo && spmv_can_fuse_dot(s) && spmv_can_split(s->A)) {
     // :122-126 with the halo exchange hidden behind the interior tiles: the exchange (pack,
     // send/recv into the tail of p) AND the few halo-touching tiles that need it run on a
@@ -408,7 +445,7 @@ static void loop_body(sb_cg* s, int k)
     // the other rank's SpMV, and with it its push, off the CUs), and on ranks with a GPU each, where it should save the
     // ~4.5 us launch, it cannot be measured from this box.
     sb_halo* h = s->halo;
-    static const bool pushInside = getenv("SB_HALO_PUSH_INSIDE") && atoi(getenv("SB_HALO_PUSH_INSIDE")) != 0;
+    const bool pushInside = g.pushInside;
     HaloWait hw;
     memset(&hw, 0, sizeof hw);
     if (pushInside) {
@@ -553,6 +590,7 @@ int sb_cg_finish(sb_cg* s)
   HIP_CHECK(hipStreamSynchronize(g.stream));
   CgScalars h;
   HIP_CHECK(hipMemcpy(&h, s->S, sizeof h, hipMemcpyDeviceToHost));
+#ifdef SB_LAB
   {
     VPhase vp;
     Lead ld[2];
@@ -565,6 +603,7 @@ int sb_cg_finish(sb_cg* s)
       SB_FATAL("rank %d: the one-launch vector phase timed out waiting for its own workgroups: the GPU is shared with other "
                "work (set SB_SHARED_GPU=1 or SB_VPHASE=0 to use the separate launches)", g.rank);
   }
+#endif
   if (h.p2p_error)
     SB_FATAL("rank %d: a peer's contribution to an in-kernel all-reduce did not arrive within %lld ms "
              "(SB_P2P_TIMEOUT_MS raises the bound, SB_P2P=0 selects the RCCL all-reduce)", g.rank,

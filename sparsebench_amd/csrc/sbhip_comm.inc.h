@@ -231,6 +231,18 @@ void sb_comm_data_plane(int peer_mapped)
 }
 int sb_comm_data_plane_selected(void) { return g.p2pUse ? 1 : 0; }
 
+// Peer-mapped halo exchange, variant: 1 = the rank's halo push rides in the SpMV launch (its first 16 workgroups send
+// p[elementsToSend]; the tiles that wait for the neighbours' pushes are stored last) instead of a launch of its own --
+// one launch fewer per loop body; 0 (default; SB_HALO_PUSH_INSIDE=1 changes the default) = separate halo_push_k.
+// Bit-identical either way.  Which one is faster can only be decided with one rank per GPU (ranks sharing a GPU keep
+// each other's pushes off the CUs), so bench.py times both on a real node.  Collective, between solves.
+void sb_comm_halo_push_inside(int on)
+{
+  need_init();
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  g.pushInside = on != 0;
+}
+
 // what the RCCL communicator itself reports: out = {ranks in the communicator, this rank's id in it, HIP device it is
 // bound to}; returns 1, or 0 when there is no RCCL communicator (one rank, host transport) or the library lacks the queries
 int sb_comm_rccl_info(int out[3])

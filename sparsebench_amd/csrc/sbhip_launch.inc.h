@@ -52,6 +52,7 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
     dim3 grid(g_scs_xcd ? per * 8 : nBlocks), block(256);
     if (m->usePacked == 3 || m->usePacked == 5) {
       launch_pat(m, false, m->usePacked == 5, x, y, dotPartials, stop, part, stream ? stream : g.stream, halo);
+#ifdef SB_LAB // levels 1-3 of the compressed mirror: measured slower than level 6 at every size; lab builds only
     } else if (m->usePacked == 2) {
       const size_t shmem = (256 + (size_t)m->ldsWindow) * sizeof(double);
 #define LDS_LAUNCH(DI, DO)                                                                                   \
@@ -78,6 +79,7 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
         else PK_LAUNCH(false, false);
       }
 #undef PK_LAUNCH
+#endif // SB_LAB
     } else {
 #define SCS_LAUNCH(U, D, N)                                                                      \
   hipLaunchKernelGGL((spmv_scs64<U, D, N>), grid, block, 0, g.stream, m->chunkPtr, m->chunkLens, \
@@ -87,6 +89,7 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
     if (dot) { if (g_scs_nt) SCS_LAUNCH(U, true, true); else SCS_LAUNCH(U, true, false); }    \
     else { if (g_scs_nt) SCS_LAUNCH(U, false, true); else SCS_LAUNCH(U, false, false); }      \
   } while (0)
+#ifdef SB_LAB // unroll depths other than 4: measured equal or slower
       switch (g_scs_unroll) {
       case 1: SCS_PICK(1); break;
       case 2: SCS_PICK(2); break;
@@ -94,6 +97,9 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
       case 9: SCS_PICK(9); break;
       default: SCS_PICK(4); break;
       }
+#else
+      SCS_PICK(4);
+#endif
 #undef SCS_PICK
 #undef SCS_LAUNCH
     }
@@ -145,12 +151,19 @@ static void launch_pat(const sb_matrix* pm, bool skipPad, bool masked, const dou
       else PAT_PICK(CP, false, false, MA);      \
     }                                           \
   } while (0)
+#ifndef SB_LAB // the product ships the masked row programs (level 6) only; levels 4-5 are lab builds
+  if (!masked) SB_FATAL("levels 4-5 of the compressed mirror are compiled into lab builds only (-DSB_LAB)");
+#endif
   if ((masked ? pm->mCPT : pm->patCPT) == 8) {
     if (masked) PAT_PICK2(8, true);
+#ifdef SB_LAB
     else PAT_PICK2(8, false);
+#endif
   } else {
     if (masked) PAT_PICK2(4, true);
+#ifdef SB_LAB
     else PAT_PICK2(4, false);
+#endif
   }
 #undef PAT_PICK2
 #undef PAT_PICK

@@ -497,7 +497,9 @@ static void pattern_rows(sb_matrix* m, PatternPlan& P, const std::vector<uint32_
 // not have to wait for the halo exchange (loop_body).  4-chunk tiles: one TileHdr (48 words); 8-chunk tiles: two
 // TileHdr halves interleaved word by word into 128 words (X: the tile-level fields + chunks 0-3, Y: the per-chunk
 // fields of chunks 4-7), which the kernel fetches as one 8-byte vector load.  Returns the number of segments.
-static size_t pattern_headers(sb_matrix* m, const PatternPlan& P, uint32_t** out, uint32_t* interiorOut)
+// tileOfHdr (optional): which tile the i-th stored header describes
+static size_t pattern_headers(sb_matrix* m, const PatternPlan& P, uint32_t** out, uint32_t* interiorOut,
+    std::vector<uint32_t>* tileOfHdr = nullptr)
 {
   const uint32_t nTiles = P.nTiles, cpt = P.cpt, LONG = cpt == 8 ? 4u : 3u;
   const std::vector<uint32_t>& segPtr = P.segPtr;
@@ -554,6 +556,10 @@ static size_t pattern_headers(sb_matrix* m, const PatternPlan& P, uint32_t** out
       if (touches_halo(h.x)) h.x.flags |= PAT_TOUCHES_HALO;
     auto mid = std::stable_partition(hdrs.begin(), hdrs.end(), [&](const Pair& h) { return !(h.x.flags & PAT_TOUCHES_HALO); });
     *interiorOut = (uint32_t)(mid - hdrs.begin());
+  }
+  if (tileOfHdr) {
+    tileOfHdr->resize(nTiles);
+    for (uint32_t t = 0; t < nTiles; t++) (*tileOfHdr)[t] = hdrs[t].x.tile;
   }
   const uint32_t stride = cpt == 8 ? 128u : 48u;
   std::vector<uint32_t> words((size_t)nTiles * stride + 128, 0u);
@@ -739,7 +745,7 @@ static bool build_masked(sb_matrix* m, const PatternPlan& P)
   m->nMaskedChunks = nMasked;
   m->mDict         = Q.anyL ? 256u : 0u;
   m->mClassDict    = P.dClassDict; // (shared with the level-5 form unless the windows are the mapped ones)
-  const size_t nSegs = pattern_headers(m, Q, &m->mHdrs, &m->mInterior);
+  const size_t nSegs = pattern_headers(m, Q, &m->mHdrs, &m->mInterior, &m->mTileOfHdr);
   m->mCPT = P.cpt, m->mNTiles = P.nTiles;
   m->mBytes = (double)Q.words * 4.0 + 2.0 * 64.0 * m->nChunks + (P.mapped ? 2.0 * P.mapStride * P.nTiles : 16.0 * nSegs) +
               (double)(P.cpt == 8 ? 384 : 192) * P.nTiles + (Q.anyL ? 4096.0 * P.classes.size() : 0.0) + 192.0 * progs.size();
@@ -866,7 +872,13 @@ static bool build_masked_mapped(sb_matrix* m, uint32_t cpt, const uint32_t* chun
     return false;
   }
   m->mOwnsTables = true, m->mSegs = dSegs, m->mWindow = maxWin, m->mMapStride = P.mapStride;
-  m->mSlotMap = (uint16_t*)upload(P.slotMap.data(), P.slotMap.size() * sizeof(uint16_t));
+  { // the map in HEADER order (interior tiles first): the kernel fetches it next to the header, before it knows the tile
+    std::vector<uint16_t> byHdr(P.slotMap.size());
+    for (uint32_t hI = 0; hI < P.nTiles; hI++)
+      memcpy(byHdr.data() + (size_t)hI * P.mapStride, P.slotMap.data() + (size_t)m->mTileOfHdr[hI] * P.mapStride, (size_t)P.mapStride * sizeof(uint16_t));
+    m->mSlotMap = (uint16_t*)upload(byHdr.data(), byHdr.size() * sizeof(uint16_t));
+  }
+  m->mTileOfHdr.clear(), m->mTileOfHdr.shrink_to_fit();
   sb_free(P.dRowBase), sb_free(P.dTileClass); // (mClassDict stays)
   return true;
 }
@@ -990,6 +1002,19 @@ static void build_patterns(sb_matrix* m, const uint32_t* chunkPtr, const uint32_
   else if (level5) m->usePacked = (m->nChunks + 3) / 4 > (uint32_t)g.prop.multiProcessorCount * 8u ? 3 : 2;
 }
 
+#ifndef SB_LAB
+// The product ships two SpMV kernels per format: the reference-layout stream and the masked row programs (level 6).
+// Levels 1-5 are BUILT on the way to level 6 (value dictionary, window slots, pattern classes), but their kernels were
+// measured slower at every size and live in lab builds (-DSB_LAB) only: the streams that only those kernels
+// read are released here, and a matrix without row programs runs the reference-layout kernel.
+static void product_modes_only(sb_matrix* m)
+{
+  if (m->usePacked != 5) m->usePacked = 0;
+  sb_free(m->pidx), sb_free(m->pcodes), sb_free(m->pslots), sb_free(m->jcodes), sb_free(m->excRows);
+  m->pidx = nullptr, m->pcodes = nullptr, m->pslots = nullptr, m->jcodes = nullptr, m->excRows = nullptr;
+}
+#endif
+
 void sb_set_external_ids(const uint32_t* global_ids, uint32_t n)
 {
   g_externalIds.assign(global_ids, global_ids + (global_ids ? n : 0));
@@ -1042,6 +1067,9 @@ sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, u
   build_packed(m, val, oldToNewPerm);
   build_lds_windows(m, chunkPtr, chunkLens, colInd, val, oldToNewPerm);
   build_patterns(m, chunkPtr, chunkLens, colInd, val, oldToNewPerm);
+#ifndef SB_LAB
+  product_modes_only(m);
+#endif
   return m;
 }
 
@@ -1093,7 +1121,12 @@ static void build_crs_mirror(sb_matrix* m, const uint32_t* rowPtr, const uint32_
   }
   sb_matrix* mm = sb_scs_upload(nr, m->nc, 64, 1, nChunks, (uint32_t)total, chunkPtr.data(), chunkLens.data(),
       scol.data(), sval.data(), nullptr, nullptr);
-  if (mm->nPatClasses == 0) { // no repeating patterns: the native kernel it is
+#ifdef SB_LAB
+  const bool useless = mm->nPatClasses == 0;
+#else
+  const bool useless = mm->mHdrs == nullptr; // (the product multiplies through the mirror's row programs only)
+#endif
+  if (useless) { // no repeating patterns: the native kernel it is
     sb_matrix_free(mm);
     return;
   }
@@ -1124,12 +1157,17 @@ void sb_matrix_use_packed(sb_matrix* m, int mode)
 { // 0 reference-layout stream, 1 packed stream + gathers through the cache, 2 packed + LDS window,
   // 3 pattern codes + LDS window; a mode the matrix does not have falls to the next lower one
   // (5: the pattern kernel on masked row programs, pack.hip.h level 6)
+#ifdef SB_LAB
   if (m->fmt == 0) m->usePacked = mode >= 5 && m->mirror && m->mirror->mHdrs ? 5 : mode >= 3 && m->mirror ? 3 : 0;
   else if (mode >= 5 && m->mHdrs) m->usePacked = 5;
   else if (mode >= 3 && m->nPatClasses) m->usePacked = 3;
   else if (mode >= 2 && m->ldsWindow) m->usePacked = 2;
   else if (mode >= 1 && m->packLevel) m->usePacked = 1;
   else m->usePacked = 0;
+#else // the product: masked row programs (5) where the matrix has them, or the reference-layout stream (0)
+  const sb_matrix* pm = m->fmt == 0 ? m->mirror : m;
+  m->usePacked        = mode >= 5 && pm && pm->mHdrs ? 5 : 0;
+#endif
 }
 int sb_matrix_packed_mode(const sb_matrix* m) { return m->usePacked; }
 // the matrix whose pattern levels serve m: m itself (SCS) or its private mirror (CRS)

@@ -13,8 +13,46 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 REFDATA = os.path.join(GOLDEN, "ref")
 
 
+def lab_build():
+    """1 when the loaded libsbhip.so is a lab build (`make lab`, selected with
+    SBHIP_LIBRARY=$PWD/sparsebench_amd/lib/lab/libsbhip.so): the product plus the measured-slower alternatives"""
+    from sparsebench_amd import capi
+    return bool(capi.load().sb_lab_build())
+
+
+def modes_scs():
+    """SpMV kernel modes to walk for an SCS C=64 matrix: the product ships 5 (masked row programs) and 0 (reference layout)"""
+    return (5, 3, 2, 1, 0) if lab_build() else (5, 0)
+
+
+def fused_levels():
+    """sb_cg_set_fused levels to walk: the product ships 1 (five launches per body) and 0 (the reference's op list)"""
+    return (1, 2, 3, 0) if lab_build() else (1, 0)
+
+
+def pytest_collection_modifyitems(config, items):
+    """tests marked `lab` exercise alternatives that only lab builds contain: with the product library they are DESELECTED
+    (not skipped), so the default `-m gpu` suite is exactly what ships"""
+    if not any(i.get_closest_marker("lab") for i in items):
+        return
+    try:
+        lab = lab_build()
+    except Exception:
+        lab = False
+    if lab:
+        return
+    keep, drop = [], []
+    for i in items:
+        (drop if i.get_closest_marker("lab") else keep).append(i)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "lab: exercises measured-slower alternatives that only lab builds (`make lab`) contain; "
+                                       "deselected unless SBHIP_LIBRARY points at a lab build")
     # build what is missing (hipcc cross-compiles without a GPU; seconds)
     need = [os.path.join(ROOT, "sparsebench_amd", "lib", n)
             for n in ("libsbhip.so", "libsparsebench_host.so", "libsparsebench_crs.so",

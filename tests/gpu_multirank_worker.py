@@ -46,12 +46,13 @@ def main():
     # every kernel the matrix has: SCS C=64 levels 0..3; CRS native (0) and through its pattern mirror (3)
     vphase_seen = 0
     # (every rank walks the SAME list: what a mode is clamped to may differ from rank to rank, the number of solves must not)
-    for mode in ((5, 3, 2, 1, 0) if fmt == "scs" and Cc == 64 else (5, 3, 0) if fmt == "crs" else (0,)):
+    lab = bool(L.sb_lab_build())  # (the product: kernel modes 5 / 0 and fused 1 / 0; lab builds walk the alternatives too)
+    for mode in (((5, 3, 2, 1, 0) if lab else (5, 0)) if fmt == "scs" and Cc == 64 else ((5, 3, 0) if lab else (5, 0)) if fmt == "crs" else (0,)):
         prob.use_packed(mode)  # clamped to what the matrix has
         # 2: the vector phase as one launch (with the in-kernel all-reduce only; the test caps its grid so that the
         # grids of all ranks on the one GPU are resident together), 1: five launches per body, 0: reference op list
         # (3, scalar steps inside their consumers, is a one-rank mode -- DESIGN 4.4 says why -- and behaves as 1 here)
-        for fused in (2, 1, 0):
+        for fused in ((2, 1, 0) if lab else (1, 0)):
             cg = hostapi.CG(prob, fused=fused)
             vphase_seen += cg.vector_phase() > 0
             if os.environ.get("SB_TEST_VERBOSE"):
