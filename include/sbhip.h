@@ -123,10 +123,14 @@ void sb_spmv(const sb_matrix* m, const double* x, double* y);
 /* the SCS fast path used inside CG: x and y in the matrix's permuted row order
  * (identical to sb_spmv when sb_matrix_is_permuted() == 0) */
 void sb_spmv_native(const sb_matrix* m, const double* x, double* y);
-/* sb_spmv_native plus, fused into the same launch, the level-0 partials of the dot product x . y (one per 64 rows of the
- * device's row order; the canonical dot of DESIGN 4.3) -- what the CG loop does for p . Ap.  partials_dev: 4 * ceil(nr / 256)
- * doubles, zero-filled by the caller (entries behind the last chunk stay +0.0).  Returns 0 and does nothing when the
- * selected kernel has no fused dot (Sell-C-sigma with C != 64, native CRS). */
+/* sb_spmv_native plus, fused into the same launch, the partial sums of the dot product x . y in the canonical order of
+ * DESIGN 4.3 (rows of the device's order) -- what the CG loop does for p . Ap.  Returns which values partials_dev holds:
+ *   0  nothing: the selected kernel has no fused dot (Sell-C-sigma with C != 64, native CRS);
+ *   2  LEVEL-1 values, one per aligned 256 rows = ((q0 + q1) + q2) + q3 of four level-0 partials: ceil(nr / 256) doubles
+ *      (the product's kernels: reference-layout Sell-64 stream and masked row programs -- a block / tile combines its
+ *      chunks itself, so the scalar step that follows reads a quarter of the bytes through its single CU);
+ *   1  level-0 partials, one per 64 rows: 4 * ceil(nr / 256) doubles (lab-only kernels).
+ * partials_dev: 4 * ceil(nr / 256) doubles, zero-filled by the caller (entries behind the last group stay +0.0). */
 int sb_spmv_native_dot(const sb_matrix* m, const double* x, double* y, double* partials_dev);
 /* vector <-> permuted order of an SCS matrix: out[new] = in[old] / out[old] = in[new] */
 void sb_permute(const sb_matrix* m, const double* in_orig, double* out_perm);

@@ -247,9 +247,10 @@ __global__ __launch_bounds__(256) void spmv_scs64(const uint32_t* __restrict__ c
   if (lb >= nBlocks || stopped) return; // uniform per workgroup
   const uint32_t chunk = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
   const uint32_t lane  = threadIdx.x & 63u;
-  if (chunk >= nChunks) return;
+  const bool active    = chunk < nChunks; // wave-uniform; with DOT an idle wave of the last block still joins the combine below
+  if (!DOT && !active) return;
   double acc = 0.0;
-  {
+  if (active) {
     const uint32_t cp  = chunkPtr[chunk];
     const uint32_t len = chunkLens[chunk];
     const double* v    = val + cp + lane;
@@ -275,7 +276,19 @@ __global__ __launch_bounds__(256) void spmv_scs64(const uint32_t* __restrict__ c
       acc         = acc + vv * x[cc];
     }
   }
-  spmv_epilogue<DOT>(chunk, lane, acc, x, y, nr, dotPartials);
+  // y, and with DOT the LEVEL-1 value of the block's four chunks (a block IS an aligned 256-group of the output vector):
+  // the four waves' level-0 partials meet in LDS and are added ((q0 + q1) + q2) + q3 -- the scalar step then reads
+  // n/256 doubles instead of n/64 through its one CU (which was 1.9 of its 4.3 us: profiles/r03_scalar_anatomy.txt)
+  const uint32_t row = chunk * 64u + lane;
+  if (active && row < nr) y[row] = acc;
+  if (DOT) {
+    __shared__ double sq[4];
+    double t = (active && row < nr) ? x[row] * acc : 0.0;
+    t        = butterfly64(t);
+    if (lane == 0) sq[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) dotPartials[lb] = ((sq[0] + sq[1]) + sq[2]) + sq[3];
+  }
 }
 
 // Any C (the reference's fixtures use C = 1, 2, 4): one thread per padded row.
@@ -950,7 +963,7 @@ template <int SP, bool P2P>
 __global__ __launch_bounds__(1024) void cg_vector_phase_k(uint32_t n, double* r, double* p, const double* __restrict__ Ap,
     double* x, CgScalars* S, const double* __restrict__ pApPartials, double* rrPartials, uint32_t m,
     double* __restrict__ rr_hist, double* __restrict__ pAp_hist, VPhase* V, long long timeoutTicks, const P2PView* pv,
-    unsigned long long p2pSeq)
+    unsigned long long p2pSeq, int pApL1)
 {
   __shared__ double lds16[16];
   __shared__ double shVal;
@@ -975,7 +988,7 @@ __global__ __launch_bounds__(1024) void cg_vector_phase_k(uint32_t n, double* r,
   if (stopped) return; // every workgroup sees the same flag: it only changes in phase C, after all have read it
   // ---- A: alpha -------------------------------------------------------------------------------------
   if (blockIdx.x == 0) {
-    double total = reduce_final_1024(m, pApPartials, lds16);
+    double total = reduce_final_1024(m, pApPartials, lds16, pApL1);
     __syncthreads();
     if (P2P) total = p2p_allreduce_sum(pv, total, p2pSeq, lds16, &S->p2p_error);
     if (threadIdx.x == 0) {
@@ -1111,10 +1124,10 @@ __device__ __forceinline__ void lead_leave(Lead* Ld, unsigned long long seq)
 template <int MODE>
 __device__ __forceinline__ bool lead_step(CgScalars* S, const double* __restrict__ partials, uint32_t m,
     double* __restrict__ rr_hist, double* __restrict__ pAp_hist, Lead* Ld, unsigned long long seq, long long timeoutTicks,
-    double* lds16, double* shVal, int* shFlag, double& value, int& stop)
+    double* lds16, double* shVal, int* shFlag, double& value, int& stop, int l1 = 0)
 {
   if (blockIdx.x == 0) {
-    const double total = reduce_final_1024(m, partials, lds16);
+    const double total = reduce_final_1024(m, partials, lds16, l1);
     if (threadIdx.x == 0) {
       cg_apply<MODE>(S, total, rr_hist, pAp_hist, 1);
       vp_store(&Ld->valueBits, (unsigned long long)__double_as_longlong(MODE == 2 ? S->alpha : S->beta));
@@ -1138,7 +1151,7 @@ __device__ __forceinline__ bool lead_step(CgScalars* S, const double* __restrict
 // = cg_scalar_k<2> followed by the r update (cg_update_r_k's arithmetic, level-0 partials), element for element
 __global__ __launch_bounds__(1024) void cg_lead_r_k(uint32_t n, const double* __restrict__ Ap, double* r, CgScalars* S,
     const double* __restrict__ pApPartials, double* __restrict__ rrPartials, uint32_t m, double* __restrict__ rr_hist,
-    double* __restrict__ pAp_hist, Lead* Ld, long long timeoutTicks)
+    double* __restrict__ pAp_hist, Lead* Ld, long long timeoutTicks, int pApL1)
 {
   __shared__ double lds16[16];
   __shared__ double shVal;
@@ -1160,7 +1173,7 @@ __global__ __launch_bounds__(1024) void cg_lead_r_k(uint32_t n, const double* __
   if (stopped) return; // (the same decision in every workgroup: nobody counts, the counter stays)
   double alpha;
   int st;
-  if (!lead_step<2>(S, pApPartials, m, rr_hist, pAp_hist, Ld, seq, timeoutTicks, lds16, &shVal, &shFlag, alpha, st)) return; // (fatal at the host)
+  if (!lead_step<2>(S, pApPartials, m, rr_hist, pAp_hist, Ld, seq, timeoutTicks, lds16, &shVal, &shFlag, alpha, st, pApL1)) return; // (fatal at the host)
   const double nalpha = -alpha;
   bool have = pair0;
   while (have) {

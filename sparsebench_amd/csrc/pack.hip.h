@@ -916,6 +916,9 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
   auto xread = [&](uint32_t o) -> double { // o: LDS byte address
     return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lds) + o);
   };
+  double pl0[CW]; // (DOT, MASKED) the wave's level-0 partials of x . y; +0.0 for chunks past the end
+#pragma unroll
+  for (int c = 0; c < CW; c++) pl0[c] = 0.0;
 #pragma unroll
   for (int c = 0; c < CW; c++) {
     if (chunk[c] >= nChunks) continue; // wave-uniform; inactive waves only helped staging
@@ -1063,7 +1066,24 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
     if (DOT) {
       double t2 = row[c] < nr ? xrow[c] * acc : 0.0;
       t2        = butterfly64(t2);
-      if (lane == 0) dotPartials[chunk[c]] = t2;
+      if (MASKED) pl0[c] = t2;
+      else if (lane == 0) dotPartials[chunk[c]] = t2;
+    }
+  }
+  // (MASKED) the tile's LEVEL-1 values ((q0 + q1) + q2) + q3 of its aligned groups of four chunks: the waves' level-0
+  // partials meet in LDS (the 8-entry pad between the tables and the window: the masked form has no exception entries)
+  // behind ONE barrier at the end of the tile's life, and the scalar step reads n/256 doubles instead of n/64 -- through
+  // its single CU that was 1.9 of its 4.3 us (profiles/r03_scalar_anatomy.txt).  Same additions, same order, same bits.
+  if (DOT && MASKED) {
+    double* sq = reinterpret_cast<double*>(se); // 16 doubles
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < CW; c++) sq[wv + 4u * (uint32_t)c] = pl0[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)CW) {
+      const uint32_t gq = threadIdx.x, group = tile * (uint32_t)CW + gq;
+      if (group < ((nChunks + 3u) >> 2)) dotPartials[group] = ((sq[4u * gq] + sq[4u * gq + 1u]) + sq[4u * gq + 2u]) + sq[4u * gq + 3u];
     }
   }
 }

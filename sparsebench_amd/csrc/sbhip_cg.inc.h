@@ -169,6 +169,7 @@ static bool vphase_plan(sb_cg*) { return false; }
 int sb_cg_vector_phase(sb_cg* s) { return vphase_plan(s) ? s->vSP : 0; }
 
 template <int MODE> static void scalar_launch(sb_cg* s, int defer_x, const double* q, int l1 = 0);
+static int pAp_is_level1(const sb_cg* s);
 
 #ifdef SB_LAB
 
@@ -203,7 +204,7 @@ static void launch_lead_r(sb_cg* s)
 {
   const uint32_t nSpans = ((s->nr + 255u) >> 8) * 2u;
   hipLaunchKernelGGL(cg_lead_r_k, lead_grid(cg_lead_r_k, nSpans, 32) /* two spans per wave and step */, dim3(1024), 0, g.stream, s->nr, s->Ap,
-      s->r, s->S, s->partials, s->partials2, s->nPartials, s->rr_hist, s->pAp_hist, s->lead + 0, lead_timeout());
+      s->r, s->S, s->partials, s->partials2, s->nPartials, s->rr_hist, s->pAp_hist, s->lead + 0, lead_timeout(), pAp_is_level1(s));
   HIP_CHECK(hipGetLastError());
   s->betaOwed = true;
 }
@@ -231,7 +232,7 @@ static void launch_vphase(sb_cg* s)
   if (multi_rank()) seq = g.p2pSeq + 1ull, g.p2pSeq += 2ull; // two all-reduces per launch
 #define VP_LAUNCH(SPN, PP)                                                                                              \
   hipLaunchKernelGGL((cg_vector_phase_k<SPN, PP>), dim3(s->vGrid), dim3(1024), 0, g.stream, s->nr, s->r, s->p, s->Ap, s->x, \
-      s->S, s->partials, s->partials2, s->nPartials, s->rr_hist, s->pAp_hist, s->vphase, ticks, (const P2PView*)g.p2pView, seq)
+      s->S, s->partials, s->partials2, s->nPartials, s->rr_hist, s->pAp_hist, s->vphase, ticks, (const P2PView*)g.p2pView, seq, pAp_is_level1(s))
   if (multi_rank()) {
     if (s->vSP == 1) VP_LAUNCH(1, true);
     else if (s->vSP == 2) VP_LAUNCH(2, true);
@@ -340,6 +341,9 @@ template <int MODE> static void scalar_launch(sb_cg* s, int defer_x, const doubl
     HIP_CHECK(hipGetLastError());
   }
 }
+
+// 1: the SpMV's fused dot wrote LEVEL-1 values of p.Ap (one per 256 rows), 0: level-0 partials (dot pass, lab kernels)
+static int pAp_is_level1(const sb_cg* s) { return spmv_can_fuse_dot(s) && spmv_dot_kind(s->A) == 2 ? 1 : 0; }
 
 static void spmv_event(sb_cg* s)
 {
@@ -480,7 +484,7 @@ static void loop_body(sb_cg* s, int k)
     phase_mark(s, PH_R_UPDATE);
     return;
   }
-  scalar_launch<2>(s, 0, nullptr);
+  scalar_launch<2>(s, 0, nullptr, pAp_is_level1(s));
   mark(s, R_DDOT);
   phase_mark(s, PH_ALPHA);
   if (s->fused) { // r -= alpha Ap (:128) + next r.r, beta, loop test; x += alpha p (:127) is owed

@@ -177,12 +177,23 @@ void sb_spmv_native(const sb_matrix* m, const double* x, double* y)
   launch_spmv(m, x, y, nullptr, nullptr);
 }
 
-int sb_spmv_native_dot(const sb_matrix* m, const double* x, double* y, double* partials_dev)
-{ // the product with the fused level-0 partials of x . y, as the CG loop launches it for p . Ap
-  need_init();
+// which values the fused dot of the selected SpMV kernel writes: 0 none (no fused dot), 1 level-0 partials (one per 64
+// rows), 2 LEVEL-1 values (one per 256 rows: the product's two wave-per-chunk kernels combine a block's / tile's four
+// chunks themselves; the lab-only kernels keep level 0)
+static int spmv_dot_kind(const sb_matrix* m)
+{
   if (!(m->fmt == 1 ? m->C == 64 : spmv_uses_patterns(m))) return 0;
-  launch_spmv(m, x, y, partials_dev, nullptr);
+  if (m->usePacked == 5 || (m->fmt == 1 && m->usePacked == 0)) return 2;
   return 1;
+}
+
+int sb_spmv_native_dot(const sb_matrix* m, const double* x, double* y, double* partials_dev)
+{ // the product with the fused partials of x . y, as the CG loop launches it for p . Ap
+  need_init();
+  const int kind = spmv_dot_kind(m);
+  if (!kind) return 0;
+  launch_spmv(m, x, y, partials_dev, nullptr);
+  return kind;
 }
 
 void sb_permute(const sb_matrix* m, const double* in_orig, double* out_perm)
