@@ -217,9 +217,16 @@ void sbh_distribute_local(Comm* c, MMMatrix* m, MMMatrix* mLocal)
 
 /* The reference's contract (src/comm.c:311-402, src/main.c:63-70): ONLY the master has read the
  * file; the other ranks pass an uninitialised MMMatrix.  So with several ranks the master's
- * header and entries are authoritative: they travel over the setup exchange in bounded pieces
- * (an all-gather in which only the master's slice is looked at) and every rank keeps the entries
- * of its row range (reference: MPI_Bcast of the counts + MPI_Scatterv of the entries). */
+ * header and entries are authoritative.  As in the reference (MPI_Bcast of the counts +
+ * MPI_Scatterv of the entries, src/comm.c:340-383) every rank receives ONLY the entries of its own
+ * row range: the master announces the per-rank counts in one small all-gather and then sends each
+ * rank its slice through the setup exchange's all-to-all, in bounded rounds (round 2 broadcast the
+ * whole matrix to everybody through an all-gather: P times the traffic and P x 16 MiB per rank).
+ * Deviation from the reference, on purpose: startRow / stopRow are the rank's ROW RANGE (the split
+ * of src/comm.c:35-38), not the row numbers of its first / last entry (src/comm.c:385-387) -- the
+ * two differ only when a range starts or ends with empty rows, where the reference would shift
+ * the ownership of those rows (and fault on a rank without entries); a rank's vectors here always
+ * cover its whole range. */
 void commDistributeMatrix(Comm* c, MMMatrix* m, MMMatrix* mLocal)
 {
   if (c->size == 1) {
@@ -231,13 +238,35 @@ void commDistributeMatrix(Comm* c, MMMatrix* m, MMMatrix* mLocal)
     exit(EXIT_FAILURE);
   }
   const int P = c->size;
-  int hdr[4] = { 0, 0, 0, 0 }; /* nr, nnz, count (lo, hi 31-bit halves) */
-  if (commIsMaster(c)) hdr[0] = m->nr, hdr[1] = m->nnz, hdr[2] = (int)(m->count & 0x7FFFFFFF), hdr[3] = (int)(m->count >> 31);
-  int* allHdr = (int*)malloc((size_t)P * 4 * sizeof(int));
-  g_xchg->allgather_ints(g_xchg->ctx, hdr, 4, allHdr);
-  const int totalNr = allHdr[0], totalNnz = allHdr[1];
-  const size_t count = (size_t)allHdr[2] | ((size_t)allHdr[3] << 31);
-  free(allHdr);
+  /* header from the master: nr, nnz, then the number of entries of every rank's row range */
+  const int H = 2 + P;
+  int* hdr    = (int*)calloc((size_t)H, sizeof(int));
+  size_t* lo  = (size_t*)calloc((size_t)P + 1, sizeof(size_t));
+  if (commIsMaster(c)) {
+    hdr[0] = m->nr, hdr[1] = m->nnz;
+    size_t at = 0;
+    for (int r = 0; r < P; r++) { /* entries are sorted by row (MMMatrixRead) */
+      int a, b;
+      rows_of_rank(r, P, m->nr, &a, &b);
+      while (at < m->count && m->entries[at].row < a) at++;
+      lo[r] = at;
+      while (at < m->count && m->entries[at].row <= b) at++;
+      if (at - lo[r] > 0x7FFFFFFFu / 4u) {
+        fprintf(stderr, "commDistributeMatrix: rank %d's slice exceeds the setup exchange's 32-bit counts\n", r);
+        exit(EXIT_FAILURE);
+      }
+      hdr[2 + r] = (int)(at - lo[r]);
+    }
+    lo[P] = at;
+  }
+  int* allHdr = (int*)malloc((size_t)P * H * sizeof(int));
+  g_xchg->allgather_ints(g_xchg->ctx, hdr, H, allHdr);
+  const int totalNr = allHdr[0], totalNnz = allHdr[1]; /* rank 0's slice comes first */
+  const size_t mineCount = (size_t)allHdr[2 + c->rank];
+  size_t maxCount = 0;
+  for (int r = 0; r < P; r++)
+    if ((size_t)allHdr[2 + r] > maxCount) maxCount = (size_t)allHdr[2 + r];
+  free(allHdr), free(hdr);
   int first, last;
   rows_of_rank(c->rank, P, totalNr, &first, &last);
   if (commIsMaster(c))
@@ -246,26 +275,37 @@ void commDistributeMatrix(Comm* c, MMMatrix* m, MMMatrix* mLocal)
       rows_of_rank(r, P, totalNr, &a, &b);
       printf("Rank %d start %d stop %d\n", r, a, b);
     }
-  const size_t PIECE = 1u << 20; /* entries per piece: 16 MiB per rank slice */
-  int* mine   = (int*)calloc(PIECE * 4, sizeof(int));
-  int* all    = (int*)malloc((size_t)P * PIECE * 4 * sizeof(int));
-  size_t cap  = 1024, used = 0;
-  MMEntry* keep = (MMEntry*)malloc(cap * sizeof(MMEntry));
-  for (size_t at = 0; at < count; at += PIECE) {
-    const size_t n = count - at < PIECE ? count - at : PIECE;
-    if (commIsMaster(c)) memcpy(mine, m->entries + at, n * sizeof(MMEntry));
-    g_xchg->allgather_ints(g_xchg->ctx, mine, (int)(n * 4), all);
-    const MMEntry* e = (const MMEntry*)all; /* rank 0's slice comes first */
-    for (size_t i = 0; i < n; i++)
-      if (e[i].row >= first && e[i].row <= last) {
-        if (used == cap) keep = (MMEntry*)realloc(keep, (cap *= 2) * sizeof(MMEntry));
-        keep[used++] = e[i];
+  const size_t PIECE = 1u << 20; /* entries per rank and round: 16 MiB */
+  MMEntry* keep = (MMEntry*)malloc((mineCount ? mineCount : 1) * sizeof(MMEntry));
+  int *scnt = (int*)calloc((size_t)P, sizeof(int)), *sdsp = (int*)calloc((size_t)P, sizeof(int));
+  int *rcnt = (int*)calloc((size_t)P, sizeof(int)), *rdsp = (int*)calloc((size_t)P, sizeof(int));
+  int dummy[4] = { 0, 0, 0, 0 };
+  /* the master packs a round's pieces back to back (transports stage the send buffer up to its last displacement) */
+  const size_t roundCap = maxCount < PIECE ? maxCount : PIECE;
+  MMEntry* stage = commIsMaster(c) ? (MMEntry*)malloc(((size_t)P * roundCap + 1) * sizeof(MMEntry)) : NULL;
+  for (size_t at = 0; at < maxCount; at += PIECE) {
+    /* this round: entries [at, at + PIECE) of every rank's slice */
+    const size_t mineN = at < mineCount ? (mineCount - at < PIECE ? mineCount - at : PIECE) : 0;
+    if (commIsMaster(c)) {
+      size_t fill = 0;
+      for (int r = 1; r < P; r++) {
+        const size_t have = lo[r + 1] - lo[r];
+        const size_t n    = at < have ? (have - at < PIECE ? have - at : PIECE) : 0;
+        if (n) memcpy(stage + fill, m->entries + lo[r] + at, n * sizeof(MMEntry));
+        scnt[r] = (int)(n * 4), sdsp[r] = (int)(fill * 4);
+        fill += n;
       }
+      if (mineN) memcpy(keep + at, m->entries + lo[0] + at, mineN * sizeof(MMEntry)); /* its own slice: no transfer */
+    } else {
+      rcnt[0] = (int)(mineN * 4), rdsp[0] = 0;
+    }
+    g_xchg->alltoallv_ints(g_xchg->ctx, commIsMaster(c) ? (const int*)stage : dummy, scnt, sdsp,
+        commIsMaster(c) || !mineN ? dummy : (int*)(keep + at), rcnt, rdsp);
   }
-  free(mine), free(all);
+  free(stage), free(scnt), free(sdsp), free(rcnt), free(rdsp), free(lo);
   mLocal->entries  = keep;
-  mLocal->count    = used;
-  mLocal->nnz      = (int)used;
+  mLocal->count    = mineCount;
+  mLocal->nnz      = (int)mineCount;
   mLocal->startRow = first;
   mLocal->stopRow  = last;
   mLocal->nr       = last - first + 1;
