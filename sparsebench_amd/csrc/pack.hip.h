@@ -736,14 +736,11 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
     const u32x2 h2  = *(lane < (uint32_t)PAT_STOP_LANE ? hp + lane : reinterpret_cast<const u32x2*>(stop));
     hvx = h2.x, hvy = h2.y;
   }
-  // (level 6, mapped windows) the slot map is stored in HEADER order, so its address does not wait for the header: the
-  // map travels in round trip 1 next to it, and x -- which needs both -- in round trip 2 (round 2 had header -> map -> x)
+  // (level 6, mapped windows) the slot map is stored in HEADER order.  Round 3 measured fetching it NEXT TO the header
+  // (one dependent hop fewer: header | map -> x instead of header -> map -> x): 0.1-0.3 us of 18.8 (the hop is not what a
+  // tile's life is made of), for 3-5 more live registers -- which takes the HALO instantiation from 61 to 66 VGPRs, i.e.
+  // from 8 to 7 resident workgroups per CU on every rank of a multi-GPU run.  So the map is fetched behind the header.
   uint32_t dmap[WB];
-  if (MASKED && slotMap) {
-    const uint16_t* mp = slotMap + (size_t)hidx * mapStride + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < WB; k++) dmap[k] = mp[min((uint32_t)k * 256u, mapStride - 256u)];
-  }
   auto field = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)hvx, i); };
   // per-chunk field of the wave's c-th chunk (chunk wv + 4 c of the tile): half X for c = 0, half Y for c = 1
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -810,7 +807,10 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
   const double xpad = x[padCol]; // slot 0: what padding multiplies (src/matrix-SCS.c:151-155)
   double t[WB];
   const bool mappedWin = MASKED && (flags & PAT_MAPPED_WINDOW) != 0u; // uniform per workgroup
-  if (mappedWin) { // slot by slot through the map (fetched next to the header, above)
+  if (mappedWin) { // slot by slot through the map
+    const uint16_t* mp = slotMap + (size_t)hidx * mapStride + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < WB; k++) dmap[k] = mp[min((uint32_t)k * 256u, mapStride - 256u)];
 #pragma unroll
     for (int k = 0; k < WB; k++) t[k] = xcol(field(12 + min(k, 17)) + dmap[k]);
   } else if (simple) { // segment by segment: entry i of segment s -> slot first_s + i
