@@ -470,7 +470,7 @@ def run_rank(args):
 
     K, W = args.steps, args.warmup
     repeats = 1 if K >= 100 else 9  # a 1 ms window moves by a few per cent from run to run: median of 9
-    vphase, launches = 0, 5
+    vphase, launches, collectives = 0, 5, 0
 
     # ---- pre-flight ------------------------------------------------------------------------------------
     goldens = load_goldens()
@@ -532,8 +532,8 @@ def run_rank(args):
         """timed passes on one resident matrix.  modes: kernel modes to time with per-launch events; the
         first is the one `value` is quoted on.  Every mode gets a clean pass (no events) when clean_all."""
         cg = hostapi.CG(prob, fused=args.fused, graph=bool(args.graph))
-        nonlocal vphase, launches
-        vphase, launches = cg.vector_phase(), cg.launches_per_body()
+        nonlocal vphase, launches, collectives
+        vphase, launches, collectives = cg.vector_phase(), cg.launches_per_body(), cg.collectives_per_body()
 
         def timed_pass(with_spmv_events, with_phases=False):
             """exactly K loop bodies, in segments restarted from x0 = 0 outside the clock"""
@@ -642,11 +642,11 @@ def run_rank(args):
         if second_plane:  # the same K steps on the communicator's collectives (RCCL all-reduce + send/recv)
             L.sb_comm_data_plane(0)
             res_coll = measure(prob, [default])
-            launches_coll = launches
+            launches_coll, collectives_coll = launches, collectives
             L.sb_comm_data_plane(1)
             launches = None  # (set again below from the default plane's solver)
             cg_tmp = hostapi.CG(prob, fused=args.fused)
-            launches, vphase = cg_tmp.launches_per_body(), cg_tmp.vector_phase()
+            launches, vphase, collectives = cg_tmp.launches_per_body(), cg_tmp.vector_phase(), cg_tmp.collectives_per_body()
             cg_tmp.free()
         # third leg, peer-mapped halo only: the halo push inside the SpMV launch (one launch fewer per body).  Which
         # variant is faster can only be decided with one rank per GPU, i.e. by this very run on a real node; validated by
@@ -661,7 +661,7 @@ def run_rank(args):
                 launches_inside = launches
             L.sb_comm_halo_push_inside(0)
             cg_tmp = hostapi.CG(prob, fused=args.fused)
-            launches, vphase = cg_tmp.launches_per_body(), cg_tmp.vector_phase()
+            launches, vphase, collectives = cg_tmp.launches_per_body(), cg_tmp.vector_phase(), cg_tmp.collectives_per_body()
             cg_tmp.free()
         rccl = (ctypes.c_int * 3)()
         has_rccl = L.sb_comm_rccl_info(rccl) if world > 1 else 0
@@ -701,6 +701,7 @@ def run_rank(args):
                            "rccl_ranks": (rccl[0] if has_rccl else None),
                            "spmv_x_staging": ("lds_window" if default >= 2 else "l1_l2_gather (LDS staging measured neutral at 12 B/element)"),
                            "fused_dots": True, "vector_phase_one_launch": bool(vphase), "launches_per_iteration": launches,
+                           "collective_calls_per_iteration": collectives,
                            "spmv_kernel_mode_by_rank": [r["spmv_mode"] for r in per_rank],
                            "device_by_rank": [r["device"] for r in per_rank],
                            "hip_graph": bool(args.graph), "library": version},
@@ -761,7 +762,7 @@ def run_rank(args):
                     "value": world * K / c["t_clean"], "ms_per_step": 1e3 * c["t_clean"] / K,
                     "ms_per_step_repeats": [1e3 * t / K for t in c["t_repeats"]],
                     "halo_exchange": "rccl_send_recv" if args.transport == "rccl" else "host_staged_gloo",
-                    "dot_allreduce": coll, "launches_per_iteration": launches_coll,
+                    "dot_allreduce": coll, "launches_per_iteration": launches_coll, "collective_calls_per_iteration": collectives_coll,
                     "per_rank_ms_per_step": cm, "phases_us": phase_table(c["phases"]),
                     "phases_us_by_rank": [r["phases_us_rccl_only"] for r in per_rank],
                     "note": "same bricks, same K steps, peer-mapped paths switched off (sb_comm_data_plane(0)): the communicator's "

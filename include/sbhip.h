@@ -251,6 +251,10 @@ int sb_cg_vector_phase(sb_cg* s);
 /* launches per loop body the loop will use: 5 (p update | SpMV | alpha | r update | beta), 3 (fused = 3), 2 (fused = 2);
  * 0 for the reference's op list */
 int sb_cg_launches_per_body(sb_cg* s);
+/* several ranks: the count above includes the halo kernels (peer-mapped push: +1, or +0 riding in the SpMV launch; pack
+ * kernel in front of a send / recv group: +1) and, without the in-kernel all-reduce, one more kernel per dot (+2);
+ * the communicator calls themselves (2 all-reduces, 1 send-recv group) are counted here: 0 on the peer-mapped paths */
+int sb_cg_collectives_per_body(sb_cg* s);
 void sb_cg_set_graph(sb_cg* s, int use_graph);
 /* Runs solveCG's whole loop without host synchronisation; returns k exactly as
  * the reference does (src/CGSolver.c:140).  Blocking. */

@@ -31,7 +31,7 @@ SYMBOLS = [
     "sb_matrix_packed_mode", "sb_matrix_lds_window", "sb_matrix_pattern_classes", "sb_matrix_row_patterns", "sb_matrix_row_programs", "sb_comm_p2p_handle", "sb_comm_p2p_open", "sb_comm_p2p_enabled", "sb_halo_p2p_enabled", "sb_cg_start", "sb_cg_finish", "sb_cg_vector_phase", "sb_cg_launches_per_body",
     "sb_comm_init_transport", "sb_comm_p2p_reason", "sb_halo_p2p_reason",
     "sb_comm_data_plane", "sb_comm_data_plane_selected", "sb_comm_rccl_info", "sb_cg_phase_timing", "sb_cg_phase_ms",
-    "sb_comm_halo_push_inside", "sb_lab_build",
+    "sb_comm_halo_push_inside", "sb_lab_build", "sb_cg_collectives_per_body",
 ]
 
 _lib = None
@@ -139,6 +139,7 @@ def load():
         "sb_comm_data_plane_selected": (C.c_int, []),
         "sb_comm_halo_push_inside": (None, [C.c_int]),
         "sb_lab_build": (C.c_int, []),
+        "sb_cg_collectives_per_body": (C.c_int, [vp]),
         "sb_comm_rccl_info": (C.c_int, [C.POINTER(C.c_int)]),
         "sb_cg_phase_timing": (None, [vp, C.c_int]),
         "sb_cg_phase_ms": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

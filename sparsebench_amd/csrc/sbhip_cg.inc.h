@@ -187,7 +187,32 @@ static bool lead_plan(sb_cg* s)
 #else
 static bool lead_plan(sb_cg*) { return false; }
 #endif // SB_LAB
-int sb_cg_launches_per_body(sb_cg* s) { return vphase_plan(s) ? 2 : lead_plan(s) ? 3 : s->fused ? 5 : 0; }
+static bool spmv_can_fuse_dot(const sb_cg* s);
+// kernel launches per loop body.  One rank: 5 (p update | SpMV | alpha | r update | beta); 0 = the reference's op list.
+// Several ranks add the halo kernels (peer-mapped: the push, 0 with the push inside the SpMV launch, + a pull where the
+// SpMV is not the pattern kernel; otherwise the pack kernel in front of the send / recv group) and, without the in-kernel
+// all-reduce, one more kernel per dot (local reduce | all-reduce | scalar step) -- the all-reduce / send-recv calls
+// themselves are counted by sb_cg_collectives_per_body.
+int sb_cg_launches_per_body(sb_cg* s)
+{
+  const int base = vphase_plan(s) ? 2 : lead_plan(s) ? 3 : s->fused ? 5 : 0;
+  if (!multi_rank() || base == 0) return base;
+  int n = base;
+  if (s->halo) {
+    const bool inSpmv = halo_p2p_active(s->halo) && spmv_can_fuse_dot(s) && spmv_uses_patterns(s->A);
+    if (inSpmv) n += (s->halo->totalSend && !g.pushInside) ? 1 : 0;
+    else if (halo_p2p_active(s->halo)) n += (s->halo->totalSend ? 1 : 0) + (s->halo->indegree ? 1 : 0);
+    else n += s->halo->totalSend ? 1 : 0;
+  }
+  if (!p2p_dots()) n += 2;
+  return n;
+}
+// communicator calls per loop body (RCCL / transport): 2 all-reduces + 1 send-recv group without the peer-mapped paths
+int sb_cg_collectives_per_body(sb_cg* s)
+{
+  if (!multi_rank() || !s->fused) return 0;
+  return (p2p_dots() ? 0 : 2) + (s->halo && !halo_p2p_active(s->halo) ? 1 : 0);
+}
 
 #ifdef SB_LAB
 

@@ -206,6 +206,9 @@ class CG:
     def launches_per_body(self):
         return self.L.sb_cg_launches_per_body(self.ptr)
 
+    def collectives_per_body(self):
+        return self.L.sb_cg_collectives_per_body(self.ptr)
+
     def solve(self, itermax=150, eps=0.0):
         self.itermax = itermax
         return self.L.sb_cg_solve(self.ptr, itermax, eps)
