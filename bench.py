@@ -184,7 +184,7 @@ def cpu_baseline_child(workload, n, iters):
             "sample": "HPCG %d^3 CRS, %d CG loop bodies of the oracle's OpenMP restatement, 1 rank x %d threads" % (n, iters, thr.value)}
 
 
-def cpu_mpi_leg(n, iters, cores):
+def cpu_mpi_leg(n, iters, cores, rate_hint=0.0):
     """The reference's hybrid mode (MPI ranks x OpenMP threads), if this box has the MPI launcher the
     reference binary oracle/_ref/sb_ref_mpi_omp was built against.  Returns a dict or None."""
     exe = os.path.join(ROOT, "oracle", "_ref", "sb_ref_mpi_omp")
@@ -208,7 +208,9 @@ def cpu_mpi_leg(n, iters, cores):
             m = re.search(r"Solution performed (\d+) iterations and took ([0-9.]+)s", out.stdout.decode())
             return (int(m.group(1)), float(m.group(2))) if m else None
         try:
-            a = run(5 * iters + 1)  # (the reference prints its loop time with two decimals: run long enough for that)
+            # (the reference prints its loop time with two decimals: run long enough -- >= ~2 s at the OpenMP-only rate --
+            #  for that resolution not to matter; 64^3 takes 0.2 ms per iteration)
+            a = run(max(5 * iters, int(2.0 * rate_hint)) + 1)
         except Exception:
             return best
         if not a or a[1] <= 0:
@@ -245,7 +247,7 @@ def cpu_baseline(workload, n, iters):
     res["openmp_only"] = {"value": res["value"], "cores": res["cores"]}
     if workload == "hpcg" and res.get("kind") == "reference" and not os.environ.get("SB_NO_MPI_BASELINE"):
         try:
-            mpi = cpu_mpi_leg(n, iters, cores)
+            mpi = cpu_mpi_leg(n, iters, cores, rate_hint=res["value"])
         except Exception as e:
             mpi = None
             sys.stderr.write("cpu_baseline: MPI leg failed (%s)\n" % e)
