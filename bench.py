@@ -418,6 +418,8 @@ def run_rank(args):
             dist.init_process_group("gloo", rank=rank, world_size=world)
             dist.barrier()
 
+    if world > 1:  # set-up (generator, partitioner, layout) is OpenMP-parallel on the host: share the cores between the ranks
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, host_cores()[1] // world)))
     if os.environ.get("SB_BENCH_TEST_DIE_RANK") == str(rank):  # test hook: a rank that dies before the first collective
         sys.stderr.write("bench: rank %d: SB_BENCH_TEST_DIE_RANK is set, exiting with code 7 (test hook)\n" % rank)
         os._exit(7)

@@ -51,6 +51,8 @@ def main():
              (32, 1, "scs", 64, 256, PREFLIGHT_ITERS)]
     cases += [(32, P, "scs", 64, 256, PREFLIGHT_ITERS) for P in (2, 3, 4, 5, 6, 7, 8)]
     cases += [(128, P, "scs", 64, 256, PREFLIGHT_ITERS) for P in (2, 4, 8)]
+    # the bench's other formats (`--fmt crs`, `--sigma 1`): the small pre-flight problem on 1, 2, 4, 8 ranks
+    cases += [(32, P, fmt, 64, 1, PREFLIGHT_ITERS) for fmt in ("crs", "scs") for P in (1, 2, 4, 8)]
     only = sys.argv[1:]
     if only and os.path.exists(OUT):
         out = json.load(open(OUT))
