@@ -63,7 +63,43 @@ def distribute_case(H, rank, size):
     assert [e[0] for e in got] == rows.tolist()
     assert [e[1] for e in got] == g.col.tolist() and [e[2] for e in got] == g.val.tolist()
     dist.barrier()
+    # Empty rows at the edges of a rank's range (and, with enough ranks, a rank without any entry): the rank's
+    # startRow / stopRow stay its ROW RANGE (src/comm.c:35-38) -- a documented deviation from src/comm.c:385-387, which takes
+    # the first / last entry's row and would shift the ownership of the empty rows; the scatter must deliver
+    # exactly the entries of the range, in file order, also when a slice is empty.
+    n = 13
+    path2 = "/tmp/sb_empty_rows_%s.mtx" % os.environ.get("MASTER_PORT", "0")
+    base, extra = n // size, n % size
+    firsts = [r * base + min(r, extra) for r in range(size)]
+    empty = set(firsts[1:]) | {f - 1 for f in firsts[1:]} | ({n - 1} if size > 2 else set())  # rows around every rank boundary
+    if size >= 4:
+        empty |= set(range(firsts[size - 2], firsts[size - 1]))  # the second-last rank gets no entry at all
+    ents = [(i, j, 1.0 + i + 0.25 * j) for i in range(n) if i not in empty for j in (max(i - 1, 0), i, min(i + 1, n - 1)) if j == i or j != i]
+    ents = sorted(set(ents))
     if rank == 0:
+        with open(path2, "w") as f:
+            f.write("%%MatrixMarket matrix coordinate real general\n")
+            f.write("%d %d %d\n" % (n, n, len(ents)))
+            for i, j, v in ents:
+                f.write("%d %d %.17g\n" % (i + 1, j + 1, v))
+    dist.barrier()
+    mm2, loc2 = MMM(), MMM()
+    if rank == 0:
+        H.MMMatrixRead(C.byref(mm2), path2.encode())
+    else:
+        C.memset(C.byref(mm2), 0x5A, C.sizeof(mm2))
+    H.commDistributeMatrix(C.byref(comm), C.byref(mm2), C.byref(loc2))
+    lo = firsts[rank]
+    hi = (firsts[rank + 1] if rank + 1 < size else n) - 1
+    want = [e for e in ents if lo <= e[0] <= hi]
+    assert (loc2.startRow, loc2.stopRow, loc2.nr) == (lo, hi, hi - lo + 1), (loc2.startRow, loc2.stopRow, lo, hi)
+    assert loc2.totalNr == n and loc2.totalNnz == len(ents) and loc2.count == len(want) == loc2.nnz
+    assert [(loc2.entries[i].row, loc2.entries[i].col, loc2.entries[i].val) for i in range(loc2.count)] == want
+    if size >= 4:
+        assert (len(want) == 0) == (rank == size - 2)
+    dist.barrier()
+    if rank == 0:
+        os.unlink(path2)
         print("DIST_OK distribute", size, flush=True)
     dist.destroy_process_group()
 
