@@ -723,6 +723,14 @@ def run_rank(args):
                 "preflight": ({"ok": True, "checks": checks} if not args.no_preflight else {"ok": None, "skipped": "--no-preflight"}),
                 "compression": prob.pack_info(),
                 "device": L.sb_device_name().decode(),
+                "parity": {
+                    "checked_in_this_run": "pre-flight histories: closed forms exact, committed oracle histories bit for bit, all ranks identical",
+                    "bit_identical_to": "the pinned CPU oracle under the GPU's fixed dot order (tests/golden/cg_hist_tree.json; -m gpu tests at 64^3 / 128^3)",
+                    "vs_cg_with_exactly_rounded_dots": "<= 1e-12 relative per iteration at 128^3 (observed 2.2e-14; tests/golden/cg_hist_exact.json)",
+                    "vs_reference_cpu_history": "<= 1e-12 on 8^3..32^3 and on the irregular stand-in; at 64^3 / 128^3 bounded at 5e-11 / 6.5e-10: the "
+                                                "reference's own sequential ddot is 2.5e-11 / 3.2e-10 away from the exactly rounded history (its "
+                                                "summation error grows with n; no parallel order can follow it) -- north_star's 1e-12 is met against "
+                                                "the exact history at the benchmark size, not against the reference's rounding"},
             }
             if world > 1:
                 out["per_rank"] = {"ms_per_step": steps_ms, "ms_per_step_min": min(steps_ms), "ms_per_step_max": max(steps_ms),

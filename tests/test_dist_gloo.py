@@ -19,7 +19,7 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("case,size", [("hpcg", 2), ("klein", 2), ("hpcg", 4), ("distribute", 2), ("distribute", 3),
+@pytest.mark.parametrize("case,size", [("hpcg", 2), ("klein", 2), ("hpcg", 4), ("distribute", 2), ("distribute", 3), ("distribute", 4),
                                        ("irregular", 2), ("irregular", 3)])
 def test_partition_and_halo_plan_multi_process(case, size):
     env = dict(os.environ, OMP_NUM_THREADS="1")
