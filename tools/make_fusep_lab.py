@@ -31,22 +31,29 @@ def patch(path, pairs):
 TEMPLATE = ("template <int CPT, bool DOT, bool SKIPPAD, bool HALO, bool MASKED>\n"
             "__global__ __launch_bounds__(256) void spmv_scs64_pat(")
 patch(W + "/sparsebench_amd/csrc/pack.hip.h", [
-    (TEMPLATE, "__device__ const double* lab_r;\n__device__ double* lab_pnew;\n__device__ double* lab_xs;\n" + TEMPLATE),
-    # own-row operands, early (next to the row bases)
-    ("    xrow[c]  = DOT ? x[min(row[c], nr - 1u)] : 0.0;\n  }\n",
-     "    xrow[c]  = DOT ? x[min(row[c], nr - 1u)] : 0.0;\n  }\n"
-     "  double rown[CW], xown[CW];\n"
-     "#pragma unroll\n  for (int c = 0; c < CW; c++) rown[c] = lab_r[min(row[c], nr - 1u)], xown[c] = lab_xs[min(row[c], nr - 1u)];\n"),
-    ("  for (int c = 0; c < CW; c++) asm volatile(\"\" ::\"v\"(base[c]), \"v\"(xrow[c]));\n",
-     "  for (int c = 0; c < CW; c++) asm volatile(\"\" ::\"v\"(base[c]), \"v\"(xrow[c]), \"v\"(rown[c]), \"v\"(xown[c]));\n"),
-    # second staging pass
-    ("    if (threadIdx.x == 0) sx[0] = xpad;\n    if (win > 256u * WB) __builtin_trap(); // (the host builds no such window)\n",
-     "    if (threadIdx.x == 0) sx[0] = xpad;\n    if (win > 256u * WB) __builtin_trap(); // (the host builds no such window)\n"
-     "    { // LAB: the r window through the same map, then sx = r + beta sx (each thread its own slots: no barrier)\n"
-     "      const double beta = 0.5;\n"
-     "#pragma unroll\n      for (int k = 0; k < WB; k++) t[k] = lab_r[field(12 + min(k, 17)) + dmap[k]];\n"
-     "#pragma unroll\n      for (int k = 0; k < WB; k++) {\n        const uint32_t slot = (uint32_t)k * 256u + threadIdx.x;\n"
-     "        if (slot < win) sx[slot] = t[k] + beta * sx[slot];\n      }\n    }\n"),
+    (TEMPLATE, "__device__ const double* lab_r_;\n__device__ double* lab_pnew_;\n__device__ double* lab_xs_;\n"
+               "typedef const __attribute__((address_space(1))) double* gcd_t;\ntypedef __attribute__((address_space(1))) double* gd_t;\n" + TEMPLATE),
+    ("  extern __shared__ __attribute__((aligned(16))) double lds[]; // [dict][exception entries + 8][window]\n",
+     "  extern __shared__ __attribute__((aligned(16))) double lds[]; // [dict][exception entries + 8][window]\n"
+     "  const gcd_t lab_r = (gcd_t)lab_r_;\n  const gd_t lab_pnew = (gd_t)lab_pnew_, lab_xs = (gd_t)lab_xs_;\n"),
+    # variant 3 (what a product kernel would have to look like to stay within 64 VGPRs): the window in TWO halves, each
+    # half loading p AND r (16 + 16 registers), p_new = r + beta p formed in registers and stored to LDS: one more
+    # dependent round trip per tile instead of 30 more live registers
+    ("  double t[WB];\n", "  double t[16];\n"),
+    ("    for (int k = 0; k < WB; k++) t[k] = xcol(field(12 + min(k, 17)) + dmap[k]);\n",
+     "    for (int k = 0; k < 8; k++) t[k] = xcol(field(12 + min(k, 17)) + dmap[k]), t[8 + k] = lab_r[field(12 + min(k, 17)) + dmap[k]];\n"),
+    ("    for (int k = 0; k < WB; k++) {\n      const uint32_t slot = (uint32_t)k * 256u + threadIdx.x;\n      if (slot < win) sx[slot] = t[k];\n    }\n"
+     "    if (threadIdx.x == 0) sx[0] = xpad;\n",
+     "    for (int k = 0; k < 8; k++) {\n      const uint32_t slot = (uint32_t)k * 256u + threadIdx.x;\n      if (slot < win) sx[slot] = t[8 + k] + 0.5 * t[k];\n    }\n"
+     "    __builtin_amdgcn_sched_barrier(0);\n    asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n    __builtin_amdgcn_sched_barrier(0);\n"
+     "#pragma unroll\n    for (int k = 8; k < WB; k++) t[k - 8] = xcol(field(12 + min(k, 17)) + dmap[k]), t[k] = lab_r[field(12 + min(k, 17)) + dmap[k]];\n"
+     "#pragma unroll\n    for (int k = 8; k < WB; k++) {\n      const uint32_t slot = (uint32_t)k * 256u + threadIdx.x;\n      if (slot < win) sx[slot] = t[k] + 0.5 * t[k - 8];\n    }\n"
+     "    if (threadIdx.x == 0) sx[0] = xpad;\n"),
+    # own-row operands: loaded LATE (behind the staging barrier: their latency hides behind the accumulate loop)
+    ("  __syncthreads();\n  // An element costs: entry -> byte offset of its x in the window -> x -> multiply -> add.\n",
+     "  __syncthreads();\n  double rown[CW], xown[CW];\n"
+     "#pragma unroll\n  for (int c = 0; c < CW; c++) rown[c] = lab_r[min(row[c], nr - 1u)], xown[c] = lab_xs[min(row[c], nr - 1u)];\n"
+     "  // An element costs: entry -> byte offset of its x in the window -> x -> multiply -> add.\n"),
     ("    if (row[c] < nr) y[row[c]] = acc;\n",
      "    if (row[c] < nr) y[row[c]] = acc;\n"
      "    if (row[c] < nr) { lab_xs[row[c]] = xown[c] + 0.25 * xrow[c]; const double pn = rown[c] + 0.5 * xrow[c]; lab_pnew[row[c]] = pn; xrow[c] = pn; }\n"),
@@ -57,8 +64,8 @@ patch(W + "/sparsebench_amd/csrc/sbhip_launch.inc.h", [
      "  { static bool once = false; if (!once) { once = true; double *a, *b, *c; size_t nb = ((size_t)pm->nc + 1024) * 8;\n"
      "      HIP_CHECK(hipMalloc(&a, nb)); HIP_CHECK(hipMalloc(&b, nb)); HIP_CHECK(hipMalloc(&c, nb));\n"
      "      HIP_CHECK(hipMemset(a, 0, nb)); HIP_CHECK(hipMemset(b, 0, nb)); HIP_CHECK(hipMemset(c, 0, nb));\n"
-     "      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(sbk::lab_r), &a, sizeof a)); HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(sbk::lab_pnew), &b, sizeof b));\n"
-     "      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(sbk::lab_xs), &c, sizeof c)); } }\n"),
+     "      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(sbk::lab_r_), &a, sizeof a)); HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(sbk::lab_pnew_), &b, sizeof b));\n"
+     "      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(sbk::lab_xs_), &c, sizeof c)); } }\n"),
 ])
 os.makedirs(ROOT + "/labs", exist_ok=True)
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
