@@ -474,7 +474,7 @@ def run_rank(args):
 
     K, W = args.steps, args.warmup
     repeats = 1 if K >= 100 else 9  # a 1 ms window moves by a few per cent from run to run: median of 9
-    vphase, launches, collectives = 0, 5, 0
+    vphase, launches, collectives, fuse_p = 0, 5, 0, 0
 
     # ---- pre-flight ------------------------------------------------------------------------------------
     goldens = load_goldens()
@@ -494,7 +494,7 @@ def run_rank(args):
             if own:
                 with quiet_stdout():
                     pr = hostapi.Problem("generate", nn, nn, nn, fmt=args.fmt, Cc=args.C, sigma=args.sigma, rank=rank, size=world)
-            cg = hostapi.CG(pr, fused=args.fused, graph=False)
+            cg = hostapi.CG(pr, fused=args.fused, graph=False, fuse_p=args.fuse_p)
             cg.solve(PREFLIGHT_ITERS, 0.0)
             rr, pap = cg.history()
             cg.free()
@@ -535,9 +535,9 @@ def run_rank(args):
     def measure(prob, modes, clean_all=False, phases=True):
         """timed passes on one resident matrix.  modes: kernel modes to time with per-launch events; the
         first is the one `value` is quoted on.  Every mode gets a clean pass (no events) when clean_all."""
-        cg = hostapi.CG(prob, fused=args.fused, graph=bool(args.graph))
-        nonlocal vphase, launches, collectives
-        vphase, launches, collectives = cg.vector_phase(), cg.launches_per_body(), cg.collectives_per_body()
+        cg = hostapi.CG(prob, fused=args.fused, graph=bool(args.graph), fuse_p=args.fuse_p)
+        nonlocal vphase, launches, collectives, fuse_p
+        vphase, launches, collectives, fuse_p = cg.vector_phase(), cg.launches_per_body(), cg.collectives_per_body(), cg.fuse_p()
 
         def timed_pass(with_spmv_events, with_phases=False):
             """exactly K loop bodies, in segments restarted from x0 = 0 outside the clock"""
@@ -599,8 +599,8 @@ def run_rank(args):
             if "events" in args.passes:
                 t_ev, ms, cnt, _ = timed_pass(True)
             ph = timed_pass(False, True)[3] if phases and "phases" in args.passes and (i == 0 or clean_all) else None
-            res[mode] = {"t_clean": t_clean, "t_mine": t_mine, "t_repeats": all_reps, "t_ev": t_ev,
-                         "spmv_us": 1e3 * ms / max(cnt, 1), "launches": cnt,
+            res[mode] = {"fuse_p": cg.fuse_p(), "t_clean": t_clean, "t_mine": t_mine, "t_repeats": all_reps, "t_ev": t_ev,
+                         "spmv_us": 1e3 * ms / max(cnt, 1), "launches": cnt, "launches_per_body": cg.launches_per_body(),
                          "moved": prob.stream_bytes(), "alg": prob.spmv_bytes(), "phases": ph}
         prob.use_packed(modes[0])
         cg.free()
@@ -610,7 +610,7 @@ def run_rank(args):
         """bytes the fused loop's vector kernels move per iteration.  Separate launches: p update (+ the x update
         owed by the previous body) 40 B/row, r update + r.r partials 24 B/row.  One-launch vector phase: r, Ap, p, x
         read and r, p, x written once: 56 B/row.  Plus the partials written and read back."""
-        return (56.0 if vphase else 64.0) * nr + 2 * 8.0 * (nr / 64.0)
+        return (56.0 if vphase else 64.0) * nr + 2 * 8.0 * (nr / 256.0)
 
     def phase_table(ph):
         return {k: round(v[0], 3) for k, v in ph.items()} if ph else None
@@ -649,8 +649,8 @@ def run_rank(args):
             launches_coll, collectives_coll = launches, collectives
             L.sb_comm_data_plane(1)
             launches = None  # (set again below from the default plane's solver)
-            cg_tmp = hostapi.CG(prob, fused=args.fused)
-            launches, vphase, collectives = cg_tmp.launches_per_body(), cg_tmp.vector_phase(), cg_tmp.collectives_per_body()
+            cg_tmp = hostapi.CG(prob, fused=args.fused, fuse_p=args.fuse_p)
+            launches, vphase, collectives, fuse_p = cg_tmp.launches_per_body(), cg_tmp.vector_phase(), cg_tmp.collectives_per_body(), cg_tmp.fuse_p()
             cg_tmp.free()
         # third leg, peer-mapped halo only: the halo push inside the SpMV launch (one launch fewer per body).  Which
         # variant is faster can only be decided with one rank per GPU, i.e. by this very run on a real node; validated by
@@ -664,8 +664,8 @@ def run_rank(args):
                 res_inside = measure(prob, [default])
                 launches_inside = launches
             L.sb_comm_halo_push_inside(0)
-            cg_tmp = hostapi.CG(prob, fused=args.fused)
-            launches, vphase, collectives = cg_tmp.launches_per_body(), cg_tmp.vector_phase(), cg_tmp.collectives_per_body()
+            cg_tmp = hostapi.CG(prob, fused=args.fused, fuse_p=args.fuse_p)
+            launches, vphase, collectives, fuse_p = cg_tmp.launches_per_body(), cg_tmp.vector_phase(), cg_tmp.collectives_per_body(), cg_tmp.fuse_p()
             cg_tmp.free()
         rccl = (ctypes.c_int * 3)()
         has_rccl = L.sb_comm_rccl_info(rccl) if world > 1 else 0
@@ -679,9 +679,15 @@ def run_rank(args):
             d = res[default]
             it_s = K / d["t_clean"]
             kern = kernel_name(args.fmt, default)
+            if d["fuse_p"]:
+                # the SpMV launch also takes the p update: + r and p_old read, p_new written, x read and written = 40 B/row,
+                # the same 64 B/row of vector traffic per iteration as with the separate kernel
+                kern = "spmv_prog_fusep"
+                d["moved"] += 40.0 * prob.nr
+                d["alg"] += 40.0 * prob.nr  # (the launch's operations: the SpMV of SURVEY 8d + the fused p / x update)
             tr = pmc_traffic(workload, kern, version) if world == 1 else (None, None, "N > 1")
-            cg_moved = d["moved"] + vector_bytes(prob.nr)
-            cg_alg = 96.0 * prob.nr + d["alg"]  # reference's unfused op list on its own layout
+            cg_moved = d["moved"] + vector_bytes(prob.nr) - (40.0 * prob.nr if d["fuse_p"] else 0.0)
+            cg_alg = 96.0 * prob.nr + d["alg"] - (40.0 * prob.nr if d["fuse_p"] else 0.0)  # reference's unfused op list on its own layout
             steps_ms = [r["ms_per_step"] for r in per_rank]
             out = {
                 "metric": "cg_iterations_per_s",
@@ -706,6 +712,7 @@ def run_rank(args):
                            "spmv_x_staging": ("lds_window" if default >= 2 else "l1_l2_gather (LDS staging measured neutral at 12 B/element)"),
                            "fused_dots": True, "vector_phase_one_launch": bool(vphase), "launches_per_iteration": launches,
                            "collective_calls_per_iteration": collectives,
+                           "p_update_inside_spmv": bool(d["fuse_p"]),
                            "spmv_kernel_mode_by_rank": [r["spmv_mode"] for r in per_rank],
                            "device_by_rank": [r["device"] for r in per_rank],
                            "hip_graph": bool(args.graph), "library": version},
@@ -740,7 +747,8 @@ def run_rank(args):
                 if ph_all:
                     out["phases_us_max_over_ranks"] = {k: max(p.get(k, 0.0) for p in ph_all) for k in ph_all[0]}
             out["roofline"]["note"] = (
-                "bytes = what this kernel streams (lossless compressed mirror, %.1f MB instead of the reference layout's "
+                "bytes = what this kernel streams (lossless compressed mirror" + (" + the p update's r, p, x: the launch takes p = r + beta p and "
+                "x += alpha p too" if d["fuse_p"] else "") + ", %.1f MB instead of the reference layout's "
                 "%.1f MB): a fraction of the HBM peak on MOVED bytes -- this kernel exploits the structure of the matrix (repeating row "
                 "shapes), and at this size its whole working set (mirror + five vectors) stays in the 256 MiB Infinity Cache across "
                 "iterations (profiles/r03_mall_lab.txt), so it is bound by per-tile latency chains, not by HBM; the HBM-roofline figure "
@@ -864,6 +872,8 @@ def main():
     ap.add_argument("--fused", type=int, default=1,
                     help="sb_cg_set_fused level: 1 five launches per loop body (default); 0 the reference's op list; "
                          "2 / 3 the measured-slower alternatives (lab builds only)")
+    ap.add_argument("--fuse-p", type=int, default=-1, help="the p update inside the SpMV launch where the matrix allows it: 1 / 0, "
+                                                           "-1 (default): the library's choice")
     ap.add_argument("--pack-mode", type=int, default=-1,
                     help="SpMV stream: 0 reference layout, 5 masked row programs + LDS x-window where the matrix qualifies "
                          "(default -1: the library's choice); 1-3 intermediate forms (lab builds only)")

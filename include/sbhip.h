@@ -255,6 +255,15 @@ int sb_cg_launches_per_body(sb_cg* s);
  * kernel in front of a send / recv group: +1) and, without the in-kernel all-reduce, one more kernel per dot (+2);
  * the communicator calls themselves (2 all-reduces, 1 send-recv group) are counted here: 0 on the peer-mapped paths */
 int sb_cg_collectives_per_body(sb_cg* s);
+/* The p update INSIDE the SpMV (round 3; pack.hip.h: spmv_prog_fusep): p = r + beta p (src/CGSolver.c:114; k = 1: p = r,
+ * :109), the x update the previous body owes (:127) and Ap = A p with its p.Ap values (:123-125) as ONE launch -- every tile
+ * forms p_new for its x window while it stages it and stores p_new / x for its own rows; p is double-buffered; on several
+ * ranks the halo push forms the boundary values itself.  4 launches per body instead of 5; element for element the same
+ * arithmetic in the same order: same bits.  Used where every chunk of the matrix is a masked row program with a mapped or
+ * simple window, in the default loop (fused = 1), on one rank or with the peer-mapped halo; otherwise the separate p update.
+ * on = 1 / 0 selects / deselects it, -1 = default (SB_FUSE_P, else the library's choice).  sb_cg_fuse_p: what the loop will do. */
+void sb_cg_set_fuse_p(sb_cg* s, int on);
+int sb_cg_fuse_p(sb_cg* s);
 void sb_cg_set_graph(sb_cg* s, int use_graph);
 /* Runs solveCG's whole loop without host synchronisation; returns k exactly as
  * the reference does (src/CGSolver.c:140).  Blocking. */

@@ -507,10 +507,12 @@ __global__ __launch_bounds__(1024) void cg_update_p(uint32_t n, const double* __
 }
 
 // the owed "x = x + alpha p" of the LAST body that ran (nobody comes after it)
-__global__ __launch_bounds__(256) void cg_x_finalize(uint32_t n, double* x, const double* __restrict__ p,
-    const CgScalars* __restrict__ S)
+// (p0 / p1: with the p update inside the SpMV, body k leaves p_k in buffer k & 1 and n_pAp bodies have run; otherwise p0 == p1)
+__global__ __launch_bounds__(256) void cg_x_finalize(uint32_t n, double* x, const double* __restrict__ p0,
+    const double* __restrict__ p1, const CgScalars* __restrict__ S)
 {
   if (!S->x_pending) return;
+  const double* __restrict__ p = (S->n_pAp & 1) ? p1 : p0;
   const double alpha    = S->alpha;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = x[i] + alpha * p[i];
@@ -767,15 +769,20 @@ struct HaloPush {
 };
 
 // the push of one workgroup out of nBlocks (its own kernel below; or the first workgroups of the HALO SpMV)
+// FUSEP: the values to send are not in memory yet -- the SpMV that follows forms p_new = r + beta p_old while it stages its
+// windows (pack.hip.h: spmv_prog_fusep) -- so the push forms them itself, with the same expression: x = p_old here.
+template <bool FUSEP = false>
 __device__ __forceinline__ void halo_push_block(const HaloPush& hp, const double* __restrict__ x, unsigned long long seq,
-    uint32_t block, uint32_t nBlocks)
+    uint32_t block, uint32_t nBlocks, const double* __restrict__ r = nullptr, double beta = 0.0)
 {
   const unsigned par    = (unsigned)(seq & 1ull);
   const uint32_t stride = nBlocks * blockDim.x;
   for (uint32_t i = block * blockDim.x + threadIdx.x; i < hp.n; i += stride) {
     const uint32_t d = hp.dest[i];
+    const uint32_t j = hp.packIdx[i];
+    const double v   = FUSEP ? r[j] + beta * x[j] : x[j];
     __hip_atomic_store(hp.stage[d] + (size_t)par * hp.ext[d] + hp.slot[i],
-        (unsigned long long)__double_as_longlong(x[hp.packIdx[i]]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __threadfence_system(); // this thread's stores are out before its workgroup counts itself done
   __syncthreads();
@@ -795,6 +802,13 @@ __global__ __launch_bounds__(256) void halo_push_k(HaloPush hp, const double* __
 {
   if (stop && *stop) return; // the same decision on every rank (the loop test is all-reduced)
   halo_push_block(hp, x, seq, blockIdx.x, gridDim.x);
+}
+// the push in front of spmv_prog_fusep: p_new = r + beta p_old of the boundary rows, formed here (which: k = 1, beta = 0, x = r)
+__global__ __launch_bounds__(256) void halo_push_fusep_k(HaloPush hp, const double* __restrict__ pold, const double* __restrict__ r,
+    const CgScalars* __restrict__ S, int which, unsigned long long seq)
+{
+  if (S->stop) return;
+  halo_push_block<true>(hp, pold, seq, blockIdx.x, gridDim.x, r, which ? 0.0 : S->beta);
 }
 
 __global__ __launch_bounds__(256) void halo_pull_k(const int* __restrict__ srcRank, const int* __restrict__ rdispl,

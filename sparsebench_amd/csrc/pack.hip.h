@@ -1088,4 +1088,231 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
   }
 }
 
+
+// =============================================================================
+// SpMV of the CG loop WITH the p update inside (round 3): Ap = A p_new, p_new = r + beta p_old (src/CGSolver.c:114 and :123),
+// and the x update the previous body owes (:127) -- the one vector kernel whose scalar is known before the SpMV starts.
+// A tile forms p_new for its x window while staging it (the window's r and p_old entries come out of L2, ~4.5x redundantly
+// over the tiles), stores p_new and the updated x for its OWN rows, and multiplies as spmv_scs64_pat<..., MASKED> does.  p is
+// double-buffered (other tiles still read p_old); on several ranks the halo entries of the window are the neighbours' p_new
+// values out of the staging area (their push kernels form them the same way, kernels.hip.h: halo_push_block<FUSEP>).
+// Element for element the arithmetic is cg_update_p's (a + beta * b, x + alpha * b; separate multiply and add) followed by
+// the row programs: same bits as the two kernels it replaces.
+// Only for matrices whose chunks are ALL row programs (no per-lane code words: mDict == 0) and whose windows are all of the
+// mapped (sigma > 1) or simple (<= 6 segments) kind; everything else keeps cg_update_p + spmv_scs64_pat.
+// Register budget (one workgroup = 256 threads must stay at 8 workgroups per CU: <= 64 VGPRs): the window is staged in TWO
+// halves of <= 8 slots per thread, each loading p_old AND r (16 + 16 registers) -- one dependent round trip more per tile than
+// the plain kernel, instead of 30 more live registers; no code-word prefetch, no class table, no exception entries.
+// =============================================================================
+template <int CPT, bool SKIPPAD, bool HALO, bool MAPPED>
+__global__ __launch_bounds__(256) void spmv_prog_fusep(const uint32_t* __restrict__ hdrWords, const int16_t* __restrict__ rowBase,
+    const ProgBlock* __restrict__ progs, const uint16_t* __restrict__ slotMap, uint32_t mapStride,
+    const double* __restrict__ pold, const double* __restrict__ r, double* __restrict__ pnew, double* xsol,
+    double* __restrict__ y, const CgScalars* __restrict__ S, int which, uint32_t nr, uint32_t nChunks, uint32_t firstHdr,
+    uint32_t nHdrs, uint32_t blocksPerXcd, uint32_t padCol, double* __restrict__ dotL1, HaloWait hw)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[]; // [16 doubles: level-1 combine][window]
+  double* sq = lds;
+  double* sx = lds + 16;
+  constexpr int CW   = CPT / 4;
+  constexpr int LONG = CPT == 8 ? 4 : 3;
+  constexpr int WB   = 3 * LONG + 3;
+  constexpr int H1   = 8; // slots per thread in the first half (loaded in front of the exit test)
+  if (HALO && blockIdx.x < hw.nPush) { // (uniform per workgroup) this workgroup carries the rank's halo push
+    if (S->stop) return;
+    halo_push_block<true>(*hw.push, pold, hw.seq, blockIdx.x, hw.nPush, r, which ? 0.0 : S->beta);
+    return;
+  }
+  const uint32_t bid   = HALO ? blockIdx.x - hw.nPush : blockIdx.x;
+  const uint32_t tile0 = blocksPerXcd ? xcd_block(bid, blocksPerXcd) : bid;
+  const uint32_t hidx  = firstHdr + min(tile0, nHdrs - 1u);
+  const uint32_t lane  = threadIdx.x & 63u;
+  uint32_t hvx, hvy = 0u;
+  if (CPT == 4) {
+    const uint32_t* hp = hdrWords + (size_t)hidx * 48u;
+    hvx = *(lane < (uint32_t)PAT_STOP_LANE ? hp + lane : reinterpret_cast<const uint32_t*>(&S->stop));
+  } else {
+    const u32x2* hp = reinterpret_cast<const u32x2*>(hdrWords + (size_t)hidx * 128u);
+    const u32x2 h2  = *(lane < (uint32_t)PAT_STOP_LANE ? hp + lane : reinterpret_cast<const u32x2*>(&S->stop));
+    hvx = h2.x, hvy = h2.y;
+  }
+  // the step's scalars (uniform: scalar loads, back with the header)
+  const double beta  = which ? 0.0 : S->beta; // k = 1: p = r + 0.0 * r (:109), the host passes pold = r
+  const double alpha = S->alpha;
+  const bool owed    = !which && S->x_pending != 0;
+  auto field = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)hvx, i); };
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  auto cfield = [&](int c, int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)(c == 0 ? hvx : hvy), i); };
+  const int stopped   = (int)field(PAT_STOP_LANE);
+  const uint32_t tile = field(46), flags = field(31), win = field(3);
+  if (HALO && (flags & PAT_TOUCHES_HALO) && !stopped && tile0 < nHdrs) { // wait for the neighbours' blocks
+    if ((int)threadIdx.x < hw.nsrc) {
+      const unsigned long long* f = hw.flags + (hw.seq & 1ull) * P2P_MAX + hw.src[threadIdx.x];
+      const long long t0          = wall_clock64();
+      while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != hw.seq) {
+        if (wall_clock64() - t0 > hw.timeoutTicks) {
+          atomicExch(hw.err, 1);
+          if (hw.stopw) atomicExch(hw.stopw, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __syncthreads();
+  }
+  // slot k of this thread: which column it holds, where it goes, whether it exists
+  // (the second half's map entries ride in the high halves of the first half's registers: 8 live registers instead of 15)
+  uint32_t dmap[MAPPED ? H1 : 1];
+  if (MAPPED) {
+    const uint16_t* mp = slotMap + (size_t)hidx * mapStride + threadIdx.x;
+    uint32_t lo[H1], hi[H1];
+#pragma unroll
+    for (int k = 0; k < H1; k++) {
+      lo[k] = mp[min((uint32_t)k * 256u, mapStride - 256u)];
+      hi[k] = k + H1 < WB ? (uint32_t)mp[min((uint32_t)(k + H1) * 256u, mapStride - 256u)] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < H1; k++) dmap[k] = lo[k] | (hi[k] << 16);
+  }
+  auto col_of = [&](int k) -> uint32_t {
+    if (MAPPED) return field(12 + min(k, 17)) + (k < H1 ? dmap[MAPPED ? k : 0] & 0xFFFFu : dmap[MAPPED ? k - H1 : 0] >> 16);
+    const int sI = k < 3 * LONG ? k / LONG : 3 + (k - 3 * LONG);
+    const uint32_t i = (k < 3 * LONG ? (uint32_t)(k % LONG) * 256u : 0u) + threadIdx.x;
+    const uint32_t sc = field(12 + 3 * sI), sn = field(12 + 3 * sI + 2);
+    return sn ? sc + min(i, sn - 1u) : padCol;
+  };
+  auto slot_of = [&](int k, bool& valid) -> uint32_t {
+    if (MAPPED) {
+      const uint32_t slot = (uint32_t)k * 256u + threadIdx.x;
+      valid = slot < win;
+      return slot;
+    }
+    const int sI = k < 3 * LONG ? k / LONG : 3 + (k - 3 * LONG);
+    const uint32_t i = (k < 3 * LONG ? (uint32_t)(k % LONG) * 256u : 0u) + threadIdx.x;
+    valid = i < field(12 + 3 * sI + 2);
+    return field(12 + 3 * sI + 1) + i;
+  };
+  // p_new of a window column: own columns r + beta p_old, halo columns the neighbour's p_new out of the staging area
+  double pv[H1], rv[H1];
+  uint32_t isHalo = 0u;
+#pragma unroll
+  for (int k = 0; k < H1; k++) {
+    const uint32_t c = col_of(k);
+    if (HALO) {
+      const bool h = c >= nr;
+      isHalo |= (h ? 1u : 0u) << k;
+      pv[k] = *(h ? hw.ext + (c - nr) : pold + c);
+      rv[k] = r[h ? 0u : c];
+    } else {
+      pv[k] = pold[c], rv[k] = r[c];
+    }
+  }
+  uint32_t chunk[CW], row[CW], lenf[CW];
+  int32_t base[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    chunk[c] = tile * CPT + wv + 4u * (uint32_t)c;
+    row[c]   = chunk[c] * 64u + lane;
+    lenf[c]  = cfield(c, 8 + (int)wv);
+    base[c]  = (int32_t)rowBase[chunk[c] < nChunks ? row[c] : 0u];
+  }
+#pragma unroll
+  for (int k = 0; k < H1; k++) asm volatile("" ::"v"(pv[k]), "v"(rv[k]));
+#pragma unroll
+  for (int c = 0; c < CW; c++) asm volatile("" ::"v"(base[c]));
+  if (tile0 >= nHdrs || stopped) return; // uniform per workgroup
+  // slot 0: what padding multiplies, p_new[padCol] (uniform addresses: scalar loads; formed again where a chunk needs it)
+  if (!MAPPED && threadIdx.x == 0) sx[0] = r[padCol] + beta * pold[padCol];
+#pragma unroll
+  for (int k = 0; k < H1; k++) {
+    bool valid;
+    const uint32_t slot = slot_of(k, valid);
+    const double pn     = (HALO && ((isHalo >> k) & 1u)) ? pv[k] : rv[k] + beta * pv[k];
+    if (valid) sx[slot] = pn;
+  }
+  { // second half: the same registers again (one more dependent round trip instead of 30 more live registers)
+    double pw[WB - H1], rw[WB - H1];
+    uint32_t isHalo2 = 0u;
+#pragma unroll
+    for (int k = H1; k < WB; k++) {
+      const uint32_t c = col_of(k);
+      if (HALO) {
+        const bool h = c >= nr;
+        isHalo2 |= (h ? 1u : 0u) << (k - H1);
+        pw[k - H1] = *(h ? hw.ext + (c - nr) : pold + c);
+        rw[k - H1] = r[h ? 0u : c];
+      } else {
+        pw[k - H1] = pold[c], rw[k - H1] = r[c];
+      }
+    }
+#pragma unroll
+    for (int k = H1; k < WB; k++) {
+      bool valid;
+      const uint32_t slot = slot_of(k, valid);
+      const double pn     = (HALO && ((isHalo2 >> (k - H1)) & 1u)) ? pw[k - H1] : rw[k - H1] + beta * pw[k - H1];
+      if (valid) sx[slot] = pn;
+    }
+  }
+  if (MAPPED && threadIdx.x == 0) sx[0] = r[padCol] + beta * pold[padCol]; // (behind this thread's own store to slot 0)
+  __syncthreads();
+  // own rows: p_old, r and (if the previous body owes it) x, behind the barrier so that their latency hides behind the programs
+  double rown[CW], xown[CW], xrow[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    const uint32_t rr = min(row[c], nr - 1u);
+    xrow[c] = pold[rr]; // x update, own p_new, dot
+    rown[c] = r[rr];
+    xown[c] = owed ? xsol[rr] : 0.0;
+  }
+  constexpr uint32_t sxOff = 16u * (uint32_t)sizeof(double);
+  double pl0[CW];
+#pragma unroll
+  for (int c = 0; c < CW; c++) pl0[c] = 0.0;
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    if (chunk[c] >= nChunks) continue; // wave-uniform
+    const uint32_t len    = lenf[c] & PAT_LEN_MASK;
+    double acc            = 0.0;
+    const uint32_t base8x = ((uint32_t)base[c] << 3) + sxOff;
+    const ProgBlock* pg   = progs + cfield(c, 32 + (int)wv);
+    const bool nomask     = (lenf[c] & PAT_NOPAD) != 0u; // wave-uniform: every lane has every entry
+    const char* ldsBytes  = reinterpret_cast<const char*>(lds);
+    uint32_t j0           = 0;
+    if (nomask) {
+#pragma unroll 1
+      for (; j0 + 8u <= len; j0 += 8u) prog_batch<8, false>(pg + (j0 >> 3), base8x, ldsBytes, acc);
+    } else {
+#pragma unroll 1
+      for (; j0 + 8u <= len; j0 += 8u) prog_batch<8, true>(pg + (j0 >> 3), base8x, ldsBytes, acc);
+    }
+    if (j0 + 4u < len) prog_batch<8, true>(pg + (j0 >> 3), base8x, ldsBytes, acc);
+    else if (j0 < len) prog_batch<4, true>(pg + (j0 >> 3), base8x, ldsBytes, acc);
+    if (!SKIPPAD && (lenf[c] & PAT_HASPAD)) {
+      const unsigned long long padMask =
+          (unsigned long long)cfield(c, 36 + 2 * (int)wv) | ((unsigned long long)cfield(c, 37 + 2 * (int)wv) << 32);
+      const double xpad = r[padCol] + beta * pold[padCol]; // (== sx[0]; the same two scalar loads and operations)
+      masked_add(acc, 0.0 * xpad, padMask);
+    }
+    double t2 = 0.0;
+    if (row[c] < nr) {
+      y[row[c]] = acc;
+      const double po = xrow[c], pn = rown[c] + beta * po; // cg_update_p's arithmetic for the own row
+      pnew[row[c]] = pn;
+      if (owed) xsol[row[c]] = xown[c] + alpha * po;
+      t2 = pn * acc;
+    }
+    pl0[c] = butterfly64(t2);
+  }
+  // the tile's level-1 values of p_new . Ap (as spmv_scs64_pat<..., MASKED> forms them)
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < CW; c++) sq[wv + 4u * (uint32_t)c] = pl0[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < (uint32_t)CW) {
+    const uint32_t gq = threadIdx.x, group = tile * (uint32_t)CW + gq;
+    if (group < ((nChunks + 3u) >> 2)) dotL1[group] = ((sq[4u * gq] + sq[4u * gq + 1u]) + sq[4u * gq + 2u]) + sq[4u * gq + 3u];
+  }
+}
+
 } // namespace sbk

@@ -25,6 +25,12 @@
 
 using namespace sbk;
 
+#ifndef SB_FUSE_P_DEFAULT
+#define SB_FUSE_P_DEFAULT true // the p update inside the SpMV (spmv_prog_fusep) wherever it applies: measured faster at every
+                               // size and format (128^3 sigma 256 +5 %, sigma 1 +12 %, CRS mirror +10 %, 64^3 +20 %); SB_FUSE_P=0 /
+                               // sb_cg_set_fuse_p(s, 0) keep the separate p update
+#endif
+
 #define HIP_CHECK(call)                                                                   \
   do {                                                                                    \
     hipError_t e_ = (call);                                                               \
@@ -229,6 +235,7 @@ struct sb_matrix {
   uint16_t* mSlotMap   = nullptr; // ... then: [tile][mMapStride] slot -> device column - the 256-slot block's base
   uint32_t mWindow = 0, mMapStride = 0;
   std::vector<uint32_t> mTileOfHdr; // (build time only) which tile the i-th stored header describes
+  bool mAllSimple = false;          // every window of the masked form is of the simple kind (<= 6 segments): spmv_prog_fusep
   uint32_t mCPT = 4, mNTiles = 0, mInterior = 0; // its own tile shape (level 5 may have had to take the smaller one)
   bool mOwnsTables = false;
   double mBytes  = 0.0;
@@ -266,6 +273,11 @@ struct sb_cg {
   sb_halo* halo;
   uint32_t nr, nc;
   double *r, *p, *Ap, *x, *b, *xexact;
+  // p double-buffered for the SpMV that takes the p update (pack.hip.h: spmv_prog_fusep): body k reads pbuf[(k-1) & 1] and
+  // writes pbuf[k & 1]; pbuf[0] == p
+  double* pbuf[2] = { nullptr, nullptr };
+  int fusepPlan = -1; // 1: the loop uses spmv_prog_fusep, 0: not, -1: not decided yet
+  int fusepWant = -1; // sb_cg_set_fuse_p: 1 / 0, -1: SB_FUSE_P or the library default
   CgScalars* S;
   double* partials;
   uint32_t nPartials;

@@ -51,6 +51,8 @@ sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host, con
   s->x  = (double*)sb_malloc(nb);
   s->b  = (double*)sb_malloc(nb);
   s->p  = (double*)sb_malloc((size_t)m->nc * sizeof(double)); // nc = nr + externals (src/CGSolver.c:70)
+  s->pbuf[0] = s->p;
+  s->pbuf[1] = (double*)sb_malloc((size_t)m->nc * sizeof(double)); // second p of the fused p update (fusep_plan)
   s->xexact = xexact_host ? (double*)sb_malloc(nb) : nullptr;
   double* tmp = scratch_ws(0, m->nr);
   sb_h2d(tmp, b_host, nb);
@@ -103,7 +105,7 @@ void sb_cg_free(sb_cg* s)
   for (hipEvent_t e : s->phEv) HIP_CHECK(hipEventDestroy(e));
   HIP_CHECK(hipEventDestroy(s->evLoop0));
   HIP_CHECK(hipEventDestroy(s->evLoop1));
-  sb_free(s->r), sb_free(s->Ap), sb_free(s->x), sb_free(s->b), sb_free(s->p), sb_free(s->xexact);
+  sb_free(s->r), sb_free(s->Ap), sb_free(s->x), sb_free(s->b), sb_free(s->pbuf[0]), sb_free(s->pbuf[1]), sb_free(s->xexact); // (s->p is one of the two)
   sb_free(s->S), sb_free(s->partials), sb_free(s->rr_hist), sb_free(s->pAp_hist), sb_free(s->partials2), sb_free(s->vphase), sb_free(s->lead);
   delete s;
 }
@@ -122,7 +124,7 @@ void sb_cg_set_fused(sb_cg* s, int fused)
 #ifndef SB_LAB
   fused = fused ? 1 : 0;
 #endif
-  if (s->fused != fused) drop_graph(s), s->vSP = -1, s->leadPlan = -1;
+  if (s->fused != fused) drop_graph(s), s->vSP = -1, s->leadPlan = -1, s->fusepPlan = -1;
   s->fused = fused;
 }
 
@@ -188,6 +190,20 @@ static bool lead_plan(sb_cg* s)
 static bool lead_plan(sb_cg*) { return false; }
 #endif // SB_LAB
 static bool spmv_can_fuse_dot(const sb_cg* s);
+// The p update inside the SpMV (pack.hip.h: spmv_prog_fusep; 4 launches per body: SpMV | alpha | r update | beta): where the
+// matrix allows it (spmv_fusep_possible), in the default loop (fused = 1), on one rank or with the halo over peer-mapped
+// memory (the push kernel then forms the boundary values itself; a send / recv exchange needs p in memory first).
+// SB_FUSE_P=0 keeps the separate p update.
+static bool fusep_plan(sb_cg* s)
+{
+  if (s->fusepPlan < 0) { // (the wish is decided once; whether it applies follows the matrix's kernel mode and the data plane)
+    const char* env = getenv("SB_FUSE_P");
+    s->fusepPlan    = (s->fusepWant >= 0 ? s->fusepWant != 0 : env ? atoi(env) != 0 : SB_FUSE_P_DEFAULT) ? 1 : 0;
+  }
+  bool ok = s->fusepPlan > 0 && s->fused == 1 && s->nr > 0 && !s->use_graph && spmv_fusep_possible(s->A);
+  if (ok && multi_rank()) ok = s->halo ? halo_p2p_active(s->halo) : true;
+  return ok;
+}
 // kernel launches per loop body.  One rank: 5 (p update | SpMV | alpha | r update | beta); 0 = the reference's op list.
 // Several ranks add the halo kernels (peer-mapped: the push, 0 with the push inside the SpMV launch, + a pull where the
 // SpMV is not the pattern kernel; otherwise the pack kernel in front of the send / recv group) and, without the in-kernel
@@ -195,7 +211,7 @@ static bool spmv_can_fuse_dot(const sb_cg* s);
 // themselves are counted by sb_cg_collectives_per_body.
 int sb_cg_launches_per_body(sb_cg* s)
 {
-  const int base = vphase_plan(s) ? 2 : lead_plan(s) ? 3 : s->fused ? 5 : 0;
+  const int base = vphase_plan(s) ? 2 : lead_plan(s) ? 3 : fusep_plan(s) ? 4 : s->fused ? 5 : 0;
   if (!multi_rank() || base == 0) return base;
   int n = base;
   if (s->halo) {
@@ -277,6 +293,15 @@ static void flush_beta(sb_cg*) {}
 static void launch_vphase(sb_cg*) {}
 #endif // SB_LAB
 // hipGraph replay of a loop body was measured slower (-7 % at 128^3, -13 ... -35 % at 64^3: DESIGN 4.4): lab builds only
+// 1 / 0: take / do not take the p update inside the SpMV where the matrix and the data plane allow it; -1: the default
+// (SB_FUSE_P, else the library's).  sb_cg_fuse_p: what the loop will do.
+void sb_cg_set_fuse_p(sb_cg* s, int on)
+{
+  s->fusepWant = on < 0 ? -1 : on != 0;
+  s->fusepPlan = -1;
+}
+int sb_cg_fuse_p(sb_cg* s) { return fusep_plan(s) ? 1 : 0; }
+
 void sb_cg_set_graph(sb_cg* s, int use_graph)
 {
 #ifdef SB_LAB
@@ -414,6 +439,46 @@ static void loop_body(sb_cg* s, int k)
   static const uint32_t vb = getenv("SB_VEC_BLOCK") && atoi(getenv("SB_VEC_BLOCK")) >= 64 ? (uint32_t)atoi(getenv("SB_VEC_BLOCK")) & ~63u : 1024u;
   const uint32_t capV = (uint32_t)g.prop.multiProcessorCount * (2048u / vb);
   dim3 gridV(std::max(1u, std::min(capV, (n / 2 + 1 + vb - 1) / vb))), blockV(vb);
+  if (fusep_plan(s)) {
+    // p = r + beta p (:114; k = 1: p = r, :109), the owed x update (:127), the halo exchange (:122) and Ap = A p with its p.Ap
+    // values (:123-125) in ONE launch (+ the halo push on several ranks): body k reads p_{k-1} in pbuf[(k - 1) & 1] and writes
+    // p_k into pbuf[k & 1]
+    const int which    = k == 1;
+    const double* pold = which ? s->r : s->pbuf[(k - 1) & 1];
+    double* pnew       = s->pbuf[k & 1];
+    HaloWait hw;
+    memset(&hw, 0, sizeof hw);
+    const bool halo = multi_rank() && s->halo;
+    if (halo) {
+      sb_halo* h = s->halo;
+      const unsigned long long seq = ++h->seq;
+      if (g.pushInside) hw.push = h->dPush, hw.nPush = h->totalSend ? 16u : 0u;
+      else if (h->totalSend) {
+        hipLaunchKernelGGL(halo_push_fusep_k, dim3(stream_grid(h->totalSend, 256)), dim3(256), 0, g.stream, h->push, pold, s->r,
+            (const CgScalars*)s->S, which, seq);
+        HIP_CHECK(hipGetLastError());
+      }
+      phase_mark(s, PH_HALO);
+      hw.flags = h->stage + 2 * (size_t)h->externalCount;
+      hw.ext   = reinterpret_cast<const double*>(h->stage + (seq & 1ull) * (size_t)h->externalCount);
+      hw.src = h->dSrcRank, hw.nsrc = h->indegree, hw.seq = seq, hw.err = h->err;
+      hw.stopw = &s->S->stop, hw.timeoutTicks = h->push.timeoutTicks;
+    }
+    spmv_event(s);
+    launch_spmv_fusep(s->A, pold, s->r, pnew, s->x, s->Ap, s->S, which, s->partials, halo ? &hw : nullptr);
+    spmv_event(s);
+    phase_mark(s, PH_SPMV);
+    s->p = pnew; // (host-side view: the newest p; cg_x_finalize picks the buffer of the last body that RAN from the device counters)
+    scalar_launch<2>(s, 0, nullptr, 1);
+    phase_mark(s, PH_ALPHA);
+    hipLaunchKernelGGL(cg_update_r_k, dim3(std::max(1u, std::min(capV, (((n + 255u) >> 8) + vb / 64 - 1) / (vb / 64)))), dim3(vb), 0, g.stream, n, s->Ap, s->r, s->S,
+        s->partials2, stop);
+    HIP_CHECK(hipGetLastError());
+    phase_mark(s, PH_R_UPDATE);
+    scalar_launch<1>(s, 1, s->partials2, 1);
+    phase_mark(s, PH_BETA);
+    return;
+  }
   if (k == 1) {
     if (n) hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, (double*)nullptr, s->S, 1); // p = r (:109)
     mark(s, R_WAXPBY);
@@ -575,7 +640,9 @@ void sb_cg_start(sb_cg* s, int itermax, double eps)
   s->hostS.hist_cap = s->hist_cap;
   HIP_CHECK(hipMemcpyAsync(s->S, &s->hostS, sizeof(CgScalars), hipMemcpyHostToDevice, g.stream));
   HIP_CHECK(hipMemsetAsync(s->x, 0, (size_t)n * sizeof(double), g.stream)); // x0 = 0 (:28)
-  HIP_CHECK(hipMemsetAsync(s->p, 0, (size_t)s->nc * sizeof(double), g.stream));
+  s->p = s->pbuf[0];
+  HIP_CHECK(hipMemsetAsync(s->pbuf[0], 0, (size_t)s->nc * sizeof(double), g.stream));
+  HIP_CHECK(hipMemsetAsync(s->pbuf[1], 0, (size_t)s->nc * sizeof(double), g.stream));
   mark(s, -1);
   // prologue, src/CGSolver.c:94-100
   launch_waxpby(n, 1.0, s->x, 0.0, s->x, s->p, nullptr);
@@ -612,7 +679,10 @@ int sb_cg_finish(sb_cg* s)
 {
   need_init();
   if (s->nr) { // the x update the last body left to "the next p update": nobody comes after it
-    hipLaunchKernelGGL(cg_x_finalize, dim3(stream_grid(s->nr, 256)), dim3(256), 0, g.stream, s->nr, s->x, s->p, s->S);
+    // (fused p update: body k left p_k in pbuf[k & 1]; which body ran last is on the device -- n_pAp -- not on the host)
+    const bool fp = fusep_plan(s);
+    hipLaunchKernelGGL(cg_x_finalize, dim3(stream_grid(s->nr, 256)), dim3(256), 0, g.stream, s->nr, s->x, fp ? s->pbuf[0] : s->p,
+        fp ? s->pbuf[1] : s->p, s->S);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemsetAsync(&s->S->x_pending, 0, sizeof(int), g.stream));
   }

@@ -171,6 +171,54 @@ static void launch_pat(const sb_matrix* pm, bool skipPad, bool masked, const dou
   HIP_CHECK(hipGetLastError());
 }
 
+// The SpMV that takes the p update (pack.hip.h: spmv_prog_fusep): the masked row programs are the selected kernel, EVERY
+// chunk is a row program (no per-lane code words) and every window is of the mapped or of the simple kind.
+static bool spmv_fusep_possible(const sb_matrix* m)
+{
+  if (m->usePacked != 5 || !spmv_uses_patterns(m)) return false;
+  const sb_matrix* pm = pat_of(m);
+  return pm->mHdrs && pm->mDict == 0 && pm->nMaskedChunks == pm->nChunks && (pm->mSlotMap != nullptr || pm->mAllSimple);
+}
+// Ap = A p_new with p_new = r + beta p_old formed on the way (which != 0: the first body, p_new = r + 0.0 * r), x += alpha p_old
+// where the previous body owes it, level-1 values of p_new . Ap into dotL1
+static void launch_spmv_fusep(const sb_matrix* m, const double* pold, const double* r, double* pnew, double* xsol, double* y,
+    const CgScalars* S, int which, double* dotL1, const HaloWait* halo)
+{
+  const sb_matrix* pm = pat_of(m);
+  const bool skipPad = m->fmt == 0, mapped = pm->mSlotMap != nullptr;
+  HaloWait hw;
+  memset(&hw, 0, sizeof hw);
+  if (halo) hw = *halo;
+  const uint32_t count = pm->mNTiles;
+  const uint32_t pper  = g_scs_xcd ? (count + 7) / 8 : 0;
+  const dim3 pgrid((g_scs_xcd ? pper * 8 : count) + (halo ? hw.nPush : 0u)), block(256);
+  const size_t shmem = (16 + (size_t)pm->mWindow) * sizeof(double);
+#define FP_LAUNCH(CP, SK, HA, MP)                                                                                          \
+  hipLaunchKernelGGL((spmv_prog_fusep<CP, SK, HA, MP>), pgrid, block, shmem, g.stream, pm->mHdrs, pm->mRowBase, pm->mProgs,  \
+      pm->mSlotMap, pm->mMapStride, pold, r, pnew, xsol, y, S, which, pm->nr, pm->nChunks, 0u, count, pper, pm->padCol, dotL1, hw)
+#define FP_PICK(CP, SK, HA)               \
+  do {                                    \
+    if (mapped) FP_LAUNCH(CP, SK, HA, true); \
+    else FP_LAUNCH(CP, SK, HA, false);    \
+  } while (0)
+#define FP_PICK2(CP)                      \
+  do {                                    \
+    if (skipPad) {                        \
+      if (halo) FP_PICK(CP, true, true);  \
+      else FP_PICK(CP, true, false);      \
+    } else {                              \
+      if (halo) FP_PICK(CP, false, true); \
+      else FP_PICK(CP, false, false);     \
+    }                                     \
+  } while (0)
+  if (pm->mCPT == 8) FP_PICK2(8);
+  else FP_PICK2(4);
+#undef FP_PICK2
+#undef FP_PICK
+#undef FP_LAUNCH
+  HIP_CHECK(hipGetLastError());
+}
+
 void sb_spmv_native(const sb_matrix* m, const double* x, double* y)
 {
   need_init();

@@ -499,7 +499,7 @@ static void pattern_rows(sb_matrix* m, PatternPlan& P, const std::vector<uint32_
 // fields of chunks 4-7), which the kernel fetches as one 8-byte vector load.  Returns the number of segments.
 // tileOfHdr (optional): which tile the i-th stored header describes
 static size_t pattern_headers(sb_matrix* m, const PatternPlan& P, uint32_t** out, uint32_t* interiorOut,
-    std::vector<uint32_t>* tileOfHdr = nullptr)
+    std::vector<uint32_t>* tileOfHdr = nullptr, bool* allSimpleOut = nullptr)
 {
   const uint32_t nTiles = P.nTiles, cpt = P.cpt, LONG = cpt == 8 ? 4u : 3u;
   const std::vector<uint32_t>& segPtr = P.segPtr;
@@ -556,6 +556,11 @@ static size_t pattern_headers(sb_matrix* m, const PatternPlan& P, uint32_t** out
       if (touches_halo(h.x)) h.x.flags |= PAT_TOUCHES_HALO;
     auto mid = std::stable_partition(hdrs.begin(), hdrs.end(), [&](const Pair& h) { return !(h.x.flags & PAT_TOUCHES_HALO); });
     *interiorOut = (uint32_t)(mid - hdrs.begin());
+  }
+  if (allSimpleOut) {
+    *allSimpleOut = true;
+    for (uint32_t t = 0; t < nTiles; t++)
+      if (!(hdrs[t].x.flags & PAT_SIMPLE_WINDOW)) *allSimpleOut = false;
   }
   if (tileOfHdr) {
     tileOfHdr->resize(nTiles);
@@ -745,7 +750,7 @@ static bool build_masked(sb_matrix* m, const PatternPlan& P)
   m->nMaskedChunks = nMasked;
   m->mDict         = Q.anyL ? 256u : 0u;
   m->mClassDict    = P.dClassDict; // (shared with the level-5 form unless the windows are the mapped ones)
-  const size_t nSegs = pattern_headers(m, Q, &m->mHdrs, &m->mInterior, &m->mTileOfHdr);
+  const size_t nSegs = pattern_headers(m, Q, &m->mHdrs, &m->mInterior, &m->mTileOfHdr, &m->mAllSimple);
   m->mCPT = P.cpt, m->mNTiles = P.nTiles;
   m->mBytes = (double)Q.words * 4.0 + 2.0 * 64.0 * m->nChunks + (P.mapped ? 2.0 * P.mapStride * P.nTiles : 16.0 * nSegs) +
               (double)(P.cpt == 8 ? 384 : 192) * P.nTiles + (Q.anyL ? 4096.0 * P.classes.size() : 0.0) + 192.0 * progs.size();

@@ -187,7 +187,7 @@ class Problem:
 class CG:
     """solveCG on the GPU (sb_cg_*): state in HBM, loop without host round trips."""
 
-    def __init__(self, problem, fused=True, graph=False):
+    def __init__(self, problem, fused=True, graph=False, fuse_p=-1):
         self.L = capi.load()
         self.problem = problem
         b, xe = problem.rhs()
@@ -197,6 +197,7 @@ class CG:
         # level itself (0, 1, 2; 2 = additionally the vector phase as one launch where possible)
         self.L.sb_cg_set_fused(self.ptr, int(fused))
         self.L.sb_cg_set_graph(self.ptr, int(graph))
+        self.L.sb_cg_set_fuse_p(self.ptr, int(fuse_p))  # -1: default; 1 / 0: the p update inside the SpMV where possible / not
         self.itermax = 0
 
     def vector_phase(self):
@@ -205,6 +206,10 @@ class CG:
 
     def launches_per_body(self):
         return self.L.sb_cg_launches_per_body(self.ptr)
+
+    def fuse_p(self):
+        """1: the loop takes the p update inside the SpMV launch (4 launches per body)"""
+        return self.L.sb_cg_fuse_p(self.ptr)
 
     def collectives_per_body(self):
         return self.L.sb_cg_collectives_per_body(self.ptr)

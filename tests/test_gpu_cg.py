@@ -26,17 +26,17 @@ def f(a):
     return np.array([float(v) for v in a])
 
 
-def run_gpu(filename, n, fmt, Cc, sigma, itermax, eps=0.0, fused=True, graph=False, pack_mode=None, pack_try=None):
+def run_gpu(filename, n, fmt, Cc, sigma, itermax, eps=0.0, fused=True, graph=False, pack_mode=None, pack_try=None, fuse_p=-1):
     nx, ny, nz = n if isinstance(n, tuple) else (n, n, n)
     p = hostapi.Problem(filename, nx, ny, nz, fmt=fmt, Cc=Cc, sigma=sigma)
     if pack_mode is not None:
         assert p.use_packed(pack_mode) == pack_mode
     if pack_try is not None:
         p.use_packed(pack_try)  # clamped to what the matrix has (CRS: its pattern mirror, if any)
-    cg = hostapi.CG(p, fused=fused, graph=graph)
+    cg = hostapi.CG(p, fused=fused, graph=graph, fuse_p=fuse_p)
     k = cg.solve(itermax, eps)
     rr, pap = cg.history()
-    out = dict(k=k, rr=rr, pAp=pap, x=cg.solution(), err=cg.check_residual())
+    out = dict(k=k, rr=rr, pAp=pap, x=cg.solution(), err=cg.check_residual(), fuse_p=cg.fuse_p(), launches=cg.launches_per_body())
     cg.free(), p.free()
     return out
 
@@ -63,6 +63,48 @@ def test_history_bit_identical_to_oracle_same_dot_order(gpu, fmt, Cc, sigma, n):
         assert r["err"] == o["max_err"]
 
 
+@pytest.mark.parametrize("dims,fmt,sigma", [((16, 16, 16), "scs", 1), ((128, 128, 2), "scs", 256), ((128, 128, 2), "scs", 1), ((32, 32, 32), "scs", 256),
+                                            ((128, 128, 2), "crs", 1), ((70, 3, 5), "scs", 1), ((20, 5, 33), "scs", 64), ((24, 20, 16), "scs", 4096)])
+def test_p_update_inside_the_spmv_same_bits(gpu, dims, fmt, sigma):
+    """round 3: where every chunk is a masked row program the default loop takes p = r + beta p (and the owed x update)
+    INSIDE the SpMV launch (spmv_prog_fusep: 4 launches per body; mapped windows for sigma > 1, simple ones otherwise; the
+    SKIPPAD instantiation behind the CRS mirror).  Same bits as the separate p update (sb_cg_set_fuse_p(s, 0)) and as the
+    oracle -- history, iteration count, x, residual check -- also in pieces, with an early exit through eps, and for
+    itermax 0..3 (no body / first body only: p = r + 0.0 * r)."""
+    g = po.GMatrix.generate(*dims)
+    o = po.cg(g, itermax=50, fmt=fmt, Cc=64, sigma=sigma, dot="tree", want_x=True)
+    on = run_gpu("generate", dims, fmt, 64, sigma, 50, fuse_p=1)
+    off = run_gpu("generate", dims, fmt, 64, sigma, 50, fuse_p=0)
+    assert off["fuse_p"] == 0 and off["launches"] == 5
+    for r in (on, off):
+        assert r["k"] == o["k"] and np.array_equal(r["rr"], o["rr"]) and np.array_equal(r["pAp"], o["pAp"])
+        assert np.array_equal(r["x"], o["x"][0]) and r["err"] == o["max_err"]
+    if dims[0] >= 128:
+        assert on["fuse_p"] == 1 and on["launches"] == 4  # lines of >= 128 rows: every chunk a row program
+    if not on["fuse_p"]:
+        return
+    p = hostapi.Problem("generate", *dims, fmt=fmt, Cc=64, sigma=sigma)
+    cg = hostapi.CG(p, fuse_p=1)
+    oe = po.cg(g, itermax=50, eps=1e-3, fmt=fmt, Cc=64, sigma=sigma, dot="tree", want_x=True)
+    assert cg.solve(50, 1e-3) == oe["k"] < o["k"]
+    rr, pap = cg.history()
+    assert np.array_equal(rr, oe["rr"]) and np.array_equal(pap, oe["pAp"]) and np.array_equal(cg.solution(), oe["x"][0])
+    cg.start(50, 0.0)  # in pieces: an odd and an even number of bodies behind the last piece (which p buffer is the newest)
+    for piece in (1, 2, 4, 30, 12):
+        cg.run_iters(piece)
+    assert cg.finish() == o["k"]
+    rr, pap = cg.history()
+    assert np.array_equal(rr, o["rr"]) and np.array_equal(pap, o["pAp"]) and np.array_equal(cg.solution(), o["x"][0])
+    for stop_after in (1, 2, 3, 8):  # finish() with bodies still outstanding: the owed x update uses the last p that was formed
+        ok = po.cg(g, itermax=stop_after + 1, fmt=fmt, Cc=64, sigma=sigma, dot="tree", want_x=True)
+        assert cg.solve(stop_after + 1, 0.0) == ok["k"]
+        assert np.array_equal(cg.solution(), ok["x"][0]), stop_after
+    for itermax in (0, 1, 2, 3):
+        ok = po.cg(g, itermax=itermax, fmt=fmt, Cc=64, sigma=sigma, dot="tree", want_x=True)
+        assert cg.solve(itermax, 0.0) == ok["k"] and np.array_equal(cg.history()[0], ok["rr"]) and np.array_equal(cg.solution(), ok["x"][0])
+    cg.free(), p.free()
+
+
 def test_launches_per_body_variants(gpu):
     """fused = 1 (default): five launches per body; 3: the two scalar steps ride in front of their consumers (3 launches);
     2: the one-launch vector phase (2); 0: the reference's op list.  Same bits in all of them, also when the loop is
@@ -74,7 +116,7 @@ def test_launches_per_body_variants(gpu):
     # (the product: 1 and 0; a request for the lab-only levels 2 / 3 behaves as 1 there)
     for fused, want in (((1, 5), (3, 3), (2, 2), (0, 0)) if lab_build() else ((1, 5), (0, 0), (3, 5), (2, 5))):
         p = hostapi.Problem("generate", 24, 20, 16, fmt="scs", Cc=64, sigma=1)
-        cg = hostapi.CG(p, fused=fused)
+        cg = hostapi.CG(p, fused=fused, fuse_p=0)  # (the p update inside the SpMV: test_p_update_inside_the_spmv_same_bits)
         assert cg.launches_per_body() == want
         assert cg.solve(70, 0.0) == o["k"]
         rr, pap = cg.history()
