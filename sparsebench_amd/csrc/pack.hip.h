@@ -695,7 +695,7 @@ __device__ __forceinline__ void prog_batch(const ProgBlock* __restrict__ blk, ui
 // per-chunk fields of chunks 4-7 in the same positions), fetched as ONE 8-byte vector load.
 // MASKED: the level-6 form (row programs in `progs`, signed row bases, no exception entries; rowPats / excRows unused).
 template <int CPT, bool DOT, bool SKIPPAD, bool HALO, bool MASKED>
-__global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict__ hdrWords,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(72))) /* see spmv_prog_fusep: the HALO instantiations used 83-95 */ void spmv_scs64_pat(const uint32_t* __restrict__ hdrWords,
     const uint32_t* __restrict__ stream, const uint16_t* __restrict__ rowBase,
     const PatEntry* __restrict__ classDict, const PatEntry* __restrict__ rowPats,
     const PatEntry* __restrict__ excRows, const ProgBlock* __restrict__ progs, const uint16_t* __restrict__ slotMap,
@@ -1104,8 +1104,11 @@ __global__ __launch_bounds__(256) void spmv_scs64_pat(const uint32_t* __restrict
 // halves of <= 8 slots per thread, each loading p_old AND r (16 + 16 registers) -- one dependent round trip more per tile than
 // the plain kernel, instead of 30 more live registers; no code-word prefetch, no class table, no exception entries.
 // =============================================================================
+// (amdgpu_num_sgpr: the tile kernels must keep 8 workgroups per CU, and on this stack a wave's scalar registers are allocated
+//  in 16s with 16 more on top (trap handler): above 80 the 800 per SIMD hold only 7 waves -- measured: 1792 = 7 x 256 tiles in
+//  flight at 87 SGPRs, tools/make_prof_lab_fusep.py; the compiler's own occupancy model allows ~100 and fills them freely)
 template <int CPT, bool SKIPPAD, bool HALO, bool MAPPED>
-__global__ __launch_bounds__(256) void spmv_prog_fusep(const uint32_t* __restrict__ hdrWords, const int16_t* __restrict__ rowBase,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(72))) void spmv_prog_fusep(const uint32_t* __restrict__ hdrWords, const int16_t* __restrict__ rowBase,
     const ProgBlock* __restrict__ progs, const uint16_t* __restrict__ slotMap, uint32_t mapStride,
     const double* __restrict__ pold, const double* __restrict__ r, double* __restrict__ pnew, double* xsol,
     double* __restrict__ y, const CgScalars* __restrict__ S, int which, uint32_t nr, uint32_t nChunks, uint32_t firstHdr,
