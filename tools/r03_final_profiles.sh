@@ -8,6 +8,8 @@ mkdir -p gpurun_out/prof
 python3 -c "from sparsebench_amd import srchash; print(srchash.csrc_hash())" > gpurun_out/r03_source_hash.txt
 python3 bench.py > gpurun_out/r03_bench_n1_128_scs_sigma256.json 2> gpurun_out/r03_bench_n1.err; echo "bench default rc=$?"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03_bench_n1_as_the_driver_types_it.json 2>> gpurun_out/r03_bench_n1.err; echo "bench driver-like rc=$?"
+python3 bench.py --fuse-p 0 --no-cpu > gpurun_out/r03_bench_n1_128_scs_sigma256_separate_p_update.json 2>> gpurun_out/r03_bench_n1.err; echo "bench fuse-p 0 rc=$?"
+python3 bench.py --sigma 1 --no-cpu > gpurun_out/r03_bench_n1_128_scs_sigma1.json 2>> gpurun_out/r03_bench_n1.err; echo "bench sigma 1 rc=$?"
 python3 bench.py --n 64 --sigma 1 > gpurun_out/r03_bench_n1_64_scs_sigma1.json 2>> gpurun_out/r03_bench_n1.err; echo "bench 64 rc=$?"
 python3 bench.py --fmt crs --no-cpu > gpurun_out/r03_bench_n1_128_crs.json 2>> gpurun_out/r03_bench_n1.err; echo "bench crs rc=$?"
 python3 bench.py --workload irregular --irr-sigmas 1,256 --steps 120 > gpurun_out/r03_bench_irregular.json 2>> gpurun_out/r03_bench_n1.err; echo "bench irregular rc=$?"
