@@ -33,6 +33,8 @@ JSON line.
                  sparsebench_amd/knownanswers.py), against the committed oracle histories in the GPU's dot order
                  (tests/golden/cg_hist_tree.json: bit for bit), and against every other rank's history (identical
                  bits).  Any mismatch: no rate is printed, exit code 4.  At N > 1 this runs on BOTH data planes.
+                 (irregular workload: the stand-in at 24^3 nodes against the history the reference itself produced on it,
+                 every format within 1e-12, CRS and Sell-64-1 identical bits.)
   rccl_only    = (N > 1) the same K steps timed again with the peer-mapped paths switched off
                  (sb_comm_data_plane(0): RCCL all-reduce + send/recv), so one invocation yields both curves.
   phases_us    = per-kernel breakdown of a loop body from an event after every launch (a separate pass).
@@ -810,6 +812,39 @@ def run_rank(args):
         formats = {}
         best = None
         specs = [("crs", 1)] + [("scs", s) for s in args.irr_sigmas]
+        # pre-flight: the stand-in at 24^3 nodes against the history the REFERENCE ITSELF produced on it (its own reader,
+        # convertMatrix and solveCG on the matrix exported as .mtx; tests/golden/cg_hist_irregular_ref.json): every format
+        # within north_star's 1e-12 of it, CRS and Sell-64-1 (same row order, same dot order) with identical bits
+        irr_checks, irr_problems = [], []
+        if not args.no_preflight:
+            try:
+                gold = json.load(open(os.path.join(ROOT, "tests", "golden", "cg_hist_irregular_ref.json")))["irregular24"]
+            except (OSError, ValueError, KeyError):
+                gold = None
+            if gold:
+                ref_rr, ref_pap = np.array([float(v) for v in gold["rr"]]), np.array([float(v) for v in gold["pAp"]])
+                first = None
+                for fmt, sigma in specs:
+                    with quiet_stdout():
+                        pr = hostapi.Problem("irregular", 24, 24, 24, fmt=fmt, Cc=64, sigma=sigma)
+                    cgp = hostapi.CG(pr, fused=args.fused, fuse_p=args.fuse_p)
+                    kk = cgp.solve(gold["itermax"], 0.0)
+                    rr, pap = cgp.history()
+                    cgp.free()
+                    pr.free()
+                    label = "irregular 24^3 nodes, %s sigma %d" % (fmt, sigma)
+                    dev = float(max((np.abs(rr - ref_rr) / ref_rr).max(), (np.abs(pap - ref_pap) / ref_pap).max())) if len(rr) == len(ref_rr) and len(pap) == len(ref_pap) else float("inf")
+                    rec = {"case": label, "k": kk, "max_rel_deviation_from_the_reference_history": dev, "ok": kk == gold["k"] and dev <= 1e-12}
+                    if sigma == 1:
+                        if first is None:
+                            first = (rr, pap)
+                        rec["same_bits_as_crs"] = bool(np.array_equal(rr, first[0]) and np.array_equal(pap, first[1]))
+                        rec["ok"] = rec["ok"] and rec["same_bits_as_crs"]
+                    irr_checks.append(rec)
+                    if not rec["ok"]:
+                        irr_problems.append("%s: k = %d (reference %d), deviation %.3g from the reference's history (bound 1e-12)" % (label, kk, gold["k"], dev))
+                if irr_problems:
+                    fail_preflight(irr_checks, irr_problems, "irregular_fe_%d^3_nodes" % n)
         for fmt, sigma in specs:
             with quiet_stdout():
                 prob = hostapi.Problem("irregular", n, n, n, fmt=fmt, Cc=64, sigma=sigma)
@@ -845,6 +880,7 @@ def run_rank(args):
                        "parallelism": "1d_block_row_x1", "library": version},
             "timed_repeats": repeats,
             "roofline": b["roofline"], "formats": formats, "device": L.sb_device_name().decode(),
+            "preflight": ({"ok": True, "checks": irr_checks} if irr_checks else {"ok": None, "skipped": "--no-preflight or no golden"}),
         }
 
     if rank == 0 and out is not None:

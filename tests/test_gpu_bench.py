@@ -144,4 +144,7 @@ def test_irregular_workload_line(gpu):
     for f in d["formats"].values():
         assert f["cg_iterations_per_s"] > 0 and 0 < f["roofline"]["frac"] <= 1.0 and 0 < f["fill"] <= 1.0
     assert d["value"] == max(f["cg_iterations_per_s"] for f in d["formats"].values())
+    # validated before it was timed: every format within 1e-12 of the history the REFERENCE produced on the stand-in at 24^3 nodes
+    assert d["preflight"]["ok"] and len(d["preflight"]["checks"]) == 3
+    assert all(c["ok"] and c["max_rel_deviation_from_the_reference_history"] <= 1e-12 for c in d["preflight"]["checks"])
     check_fractions(d)
