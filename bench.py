@@ -32,7 +32,8 @@ JSON line.
                  prologue, p.Ap of the first body: exact integers at any size and rank count,
                  sparsebench_amd/knownanswers.py), against the committed oracle histories in the GPU's dot order
                  (tests/golden/cg_hist_tree.json: bit for bit), and against every other rank's history (identical
-                 bits).  Any mismatch: no rate is printed, exit code 4.  At N > 1 this runs on BOTH data planes.
+                 bits).  Any mismatch: no rate is printed from that data plane (one plane only: exit code 4).  At N > 1
+                 this runs on BOTH data planes, each before it is timed.
                  (irregular workload: the stand-in at 24^3 nodes against the history the reference itself produced on it,
                  every format within 1e-12, CRS and Sell-64-1 identical bits.)
   rccl_only    = (N > 1) the same K steps timed again with the peer-mapped paths switched off
@@ -40,11 +41,17 @@ JSON line.
   phases_us    = per-kernel breakdown of a loop body from an event after every launch (a separate pass).
   K < 100      : the K-step timing is repeated and the MEDIAN is reported (timed_repeats).
 
-`python bench.py --gpus N` works as typed: the parent process starts N rank processes (one per GPU,
+`python bench.py --gpus N` works as typed: the parent process starts N worker processes (one per GPU,
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, free port) BEFORE anything touches the GPU, relays rank 0's
 single JSON line and any non-zero exit code, and never initialises HIP itself.  Under
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks already exist and each
-process is one of them.
+rank process supervises ONE worker the same way.
+
+  degraded     = (N > 1) the communicator's data plane is validated and timed FIRST; behind that checkpoint a failure of
+                 the peer-mapped plane -- wrong values in its pre-flight, a crash, a time-out -- does not lose the run: the
+                 line is then quoted on the communicator's plane (config.data_plane says which), carries a `degraded`
+                 block (what failed, exit codes, stderr tails) and the exit code is 0.  A failure of the communicator
+                 plane's own pre-flight, or of anything before the checkpoint, prints no rate and exits non-zero.
 """
 import argparse
 import contextlib
@@ -270,55 +277,134 @@ def free_port():
     return port
 
 
-def spawn_ranks(n_gpus, argv):
-    """One child per rank; this process never touches the GPU (no HIP call, no exec of a process that
-    has).  Rank 0's stdout is captured (reader thread) and its single JSON line relayed; the others'
-    stdout goes to stderr.  ALL children are polled: as soon as one exits non-zero the others -- which
-    would otherwise sit in a collective that has no time-out -- are terminated, and that rank's exit code
-    is returned.  Nothing is ever restarted or exec'd."""
+MARK = "@@sbbench "  # prefix of the worker -> supervisor lines on a worker's stdout (never relayed)
+
+
+def supervise(ranks, n_gpus, argv, own_env):
+    """N > 1: every rank's work runs in a WORKER process under a supervisor that never touches the GPU (no HIP call, no
+    exec of a process that has).  `python bench.py --gpus N`: one supervisor (this process) starts all N workers
+    (own_env: it sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* on a free port).  Under torch.distributed.run every rank
+    process is the supervisor of ONE worker that inherits its environment unchanged.
+
+    Worker stdout is captured: `MARK` lines are protocol, a line starting with "{" is rank 0's JSON line, anything else
+    goes to stderr.  ALL workers are polled: as soon as one exits non-zero the others -- which would otherwise sit in a
+    collective that has no time-out -- are terminated.  Nothing is ever restarted or exec'd.
+
+    Degraded completion (first contact with real xGMI links must yield a line if ANY validated data plane works): the
+    workers validate and time the communicator's data plane (RCCL all-reduce + send/recv) FIRST and then announce a
+    checkpoint; rank 0 hands over a provisional line quoted on that plane.  If a worker then dies, times out or
+    hangs in the peer-mapped legs, the supervisor prints the provisional line with a "degraded" block (who failed, exit
+    code, stderr tail) and exits 0 -- a rate from a plane that passed its pre-flight, labelled as such.  A failure
+    BEFORE the checkpoint (or of the pre-flight itself) is an error: no rate, the worker's exit code."""
     import threading
-    port = free_port()
-    procs = []
-    for r in range(n_gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SB_BENCH_RANK_PROCESS="1")
+    port = free_port() if own_env else None
+    procs, state = {}, {}
+    for r in ranks:
+        env = dict(os.environ, SB_BENCH_RANK_PROCESS="1")
+        if own_env:
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    chunks = []
-    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
-    rc, failed = 0, None
+        script = os.environ.get("SB_BENCH_WORKER_SCRIPT", os.path.abspath(__file__))  # (test hook: tests/test_bench_supervisor.py)
+        procs[r] = subprocess.Popen([sys.executable, script] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        state[r] = {"checkpoint": None, "provisional": None, "final": None, "err": []}
+
+    def read_out(r):
+        for raw in procs[r].stdout:
+            ln = raw.decode(errors="replace").rstrip("\n")
+            if ln.startswith(MARK + "checkpoint"):
+                state[r]["checkpoint"] = time.time()
+            elif ln.startswith(MARK + "provisional "):
+                state[r]["provisional"] = ln[len(MARK + "provisional "):]
+            elif ln.startswith("{"):
+                state[r]["final"] = ln
+            elif ln.strip():
+                sys.stderr.write(ln + "\n")
+
+    def read_err(r):
+        for raw in procs[r].stderr:
+            ln = raw.decode(errors="replace")
+            sys.stderr.write(ln)
+            state[r]["err"] = (state[r]["err"] + [ln.rstrip("\n")])[-12:]
+
+    threads = [threading.Thread(target=f, args=(r,), daemon=True) for r in ranks for f in (read_out, read_err)]
+    for t in threads:
+        t.start()
+    # bounds: the whole run, and the legs behind the checkpoint (seconds of work when healthy)
+    t_total = float(os.environ.get("SB_BENCH_TIMEOUT_S", "1500"))
+    t_after = float(os.environ.get("SB_BENCH_AFTER_CHECKPOINT_S", "240"))
+    t0 = time.time()
+    rc, failed, why = 0, None, None
+    # (a supervisor that is told to stop -- torch.distributed.run ends the group when one rank fails -- ends its workers)
+    import signal
+    stop = {"sig": None}
+    old = {sg: signal.signal(sg, lambda n, f: stop.__setitem__("sig", n)) for sg in (signal.SIGTERM, signal.SIGINT)}
     try:
         while True:
-            codes = [p.poll() for p in procs]
-            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            codes = {r: p.poll() for r, p in procs.items()}
+            bad = [(r, c) for r, c in codes.items() if c not in (None, 0)]
             if bad:
                 failed, rc = bad[0]
+                why = "rank %d exited with code %d" % (failed, rc)
                 break
-            if all(c == 0 for c in codes):
+            if all(c == 0 for c in codes.values()):
+                break
+            now = time.time()
+            cps = [state[r]["checkpoint"] for r in ranks]
+            if stop["sig"] is not None:
+                failed, rc, why = -1, 128 + stop["sig"], "the supervisor received signal %d" % stop["sig"]
+                break
+            if now - t0 > t_total:
+                failed, rc, why = -1, 124, "the run exceeded SB_BENCH_TIMEOUT_S = %.0f s" % t_total
+                break
+            if all(cps) and now - max(cps) > t_after:
+                failed, rc, why = -1, 124, "the legs behind the checkpoint exceeded SB_BENCH_AFTER_CHECKPOINT_S = %.0f s" % t_after
                 break
             time.sleep(0.05)
     finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
         if failed is not None:
-            sys.stderr.write("bench: rank %d exited with code %d; ending the other ranks\n" % (failed, rc))
+            sys.stderr.write("bench: %s; ending the other ranks\n" % why)
             time.sleep(1.0)  # (let ranks that are failing for the same reason print their own message)
-        for p in procs:  # end exactly the processes we started
+        for p in procs.values():  # end exactly the processes we started
             if p.poll() is None:
                 p.terminate()
-        for p in procs:
+        for p in procs.values():
             try:
                 p.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 p.kill()
-    reader.join(timeout=10)
-    out0 = b"".join(c for c in chunks if c)
-    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.startswith("{")]
-    if lines:
-        print(lines[-1], flush=True)
-    elif rc == 0:
-        rc = 3
-        sys.stderr.write("bench: rank 0 printed no JSON line\n")
+    for t in threads:
+        t.join(timeout=10)
+    mine0 = 0 in state
+    if failed is None:
+        if mine0:
+            if state[0]["final"]:
+                print(state[0]["final"], flush=True)
+            else:
+                rc = 3
+                sys.stderr.write("bench: rank 0 printed no JSON line\n")
+        return rc
+    if stop["sig"] is None and all(state[r]["checkpoint"] for r in ranks):
+        # behind the checkpoint: the communicator's plane was validated and timed on every rank
+        if mine0:
+            if state[0]["final"]:  # (rank 0 had finished; somebody else failed on the way out)
+                print(state[0]["final"], flush=True)
+            elif state[0]["provisional"]:
+                line = json.loads(state[0]["provisional"])
+                tails = {str(r): state[r]["err"][-6:] for r in ranks if procs[r].returncode not in (0, None, -15)}
+                line["degraded"] = {"why": why + " in the legs behind the communicator-plane checkpoint",
+                                    "value_is_quoted_on": line["config"].get("data_plane"),
+                                    "exit_codes": {str(r): procs[r].returncode for r in ranks}, "stderr_tail": tails}
+                print(json.dumps(line), flush=True)
+            else:
+                sys.stderr.write("bench: checkpoint without a provisional line\n")
+                return rc
+        sys.stderr.write("bench: DEGRADED completion (%s): the line is quoted on the communicator's data plane\n" % why)
+        return 0
+    if mine0 and state[0]["final"]:  # a failure line (pre-flight): relay it, keep the exit code
+        print(state[0]["final"], flush=True)
     return rc
 
 
@@ -627,33 +713,81 @@ def run_rank(args):
         second_plane = world > 1 and (p2p_dots or p2p_halo) and not args.no_rccl_leg
         coll = "rccl" if args.transport == "rccl" else "host_staged_gloo"
 
-        # pre-flight on every data plane that will be timed, before anything is timed
-        checks, problems = [], []
-        if not args.no_preflight:
-            for plane in ([1, 0] if second_plane else [1]):
-                if world > 1:
-                    L.sb_comm_data_plane(plane)
-                name = "one GPU" if world == 1 else ("peer-mapped data plane" if plane and (p2p_dots or p2p_halo) else "%s data plane" % coll)
-                recs, bad = preflight(name, prob)
-                checks += recs
-                problems += bad
-            if world > 1:
-                L.sb_comm_data_plane(1)
-            if problems:
-                fail_preflight(checks, problems, workload)
+        supervised = bool(os.environ.get("SB_BENCH_RANK_PROCESS"))
 
-        modes = [default] + ([0] if default != 0 else [])
-        res = measure(prob, modes, clean_all=(world == 1) or args.all_clean)
-        res_coll = None
-        if second_plane:  # the same K steps on the communicator's collectives (RCCL all-reduce + send/recv)
+        def plane_name(plane):
+            return "one GPU" if world == 1 else ("peer-mapped data plane" if plane and (p2p_dots or p2p_halo) else "%s data plane" % coll)
+
+        def compact_line(c, plane, recs, steps_ms):
+            """a complete line of the contract quoted on ONE validated data plane (the provisional line handed to the
+            supervisor behind the communicator-plane checkpoint; the degraded line when the peer-mapped plane fails its pre-flight)"""
+            it = K / c["t_clean"]
+            return {"metric": "cg_iterations_per_s", "value": world * it,
+                    "unit": "iterations/s (one iteration = one %d^3-brick CG step; summed over GPUs)" % n,
+                    "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * c["t_clean"] / K,
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                    "config": {"workload": workload, "rows_per_gpu": prob.nr, "nnz_per_gpu": prob.nnzTrue, "index_type": "u32",
+                               "parallelism": "1d_block_row_x%d" % world, "data_plane": plane_name(plane),
+                               "halo_exchange": "rccl_send_recv" if args.transport == "rccl" else "host_staged_gloo",
+                               "dot_allreduce": coll, "launches_per_iteration": c["launches_per_body"],
+                               "p_update_inside_spmv": bool(c["fuse_p"]), "library": version},
+                    "timed_repeats": repeats, "ms_per_step_repeats": [1e3 * t / K for t in c["t_repeats"]],
+                    "global_iterations_per_s": it, "phases_us": phase_table(c["phases"]),
+                    "per_rank": {"ms_per_step": steps_ms}, "preflight": {"ok": True, "checks": recs},
+                    "device": L.sb_device_name().decode(), "cpu_baseline": None}
+
+        # pre-flight on every data plane that will be timed, before that plane is timed.  N > 1 with both planes up: the
+        # communicator's plane FIRST (validated, timed, handed to the supervisor as a provisional line: the checkpoint), so
+        # that a failure of the peer-mapped plane on its first contact with real links still leaves a validated rate.
+        checks, problems = [], []
+        res_coll, degraded = None, None
+        if second_plane:
             L.sb_comm_data_plane(0)
+            if not args.no_preflight:
+                checks, problems = preflight(plane_name(0), prob)
+                if problems:
+                    fail_preflight(checks, problems, workload)
             res_coll = measure(prob, [default])
             launches_coll, collectives_coll = launches, collectives
             L.sb_comm_data_plane(1)
-            launches = None  # (set again below from the default plane's solver)
-            cg_tmp = hostapi.CG(prob, fused=args.fused, fuse_p=args.fuse_p)
-            launches, vphase, collectives, fuse_p = cg_tmp.launches_per_body(), cg_tmp.vector_phase(), cg_tmp.collectives_per_body(), cg_tmp.fuse_p()
-            cg_tmp.free()
+            coll_ms = gather(1e3 * res_coll[default]["t_mine"] / K)
+            provisional = compact_line(res_coll[default], 0, list(checks), coll_ms) if rank == 0 else None
+            if supervised:
+                if rank == 0:
+                    print(MARK + "provisional " + json.dumps(provisional), flush=True)
+                barrier()
+                print(MARK + "checkpoint", flush=True)
+            if os.environ.get("SB_BENCH_TEST_DIE_AFTER_CHECKPOINT") == str(rank):  # test hook: a crash in the peer-mapped legs
+                sys.stderr.write("bench: rank %d: SB_BENCH_TEST_DIE_AFTER_CHECKPOINT is set, exiting with code 9 (test hook)\n" % rank)
+                os._exit(9)
+        if not args.no_preflight:
+            recs, bad = preflight(plane_name(1), prob)
+            checks += recs
+            if bad and second_plane:
+                # the peer-mapped plane gives WRONG results here, the communicator's plane passed: no rate from the former, the
+                # line is quoted on the latter and says so (exit code 0: a validated rate; the failure is in the line and on stderr)
+                degraded = bad
+            elif bad:
+                fail_preflight(checks, bad, workload)
+        if degraded:
+            if rank == 0:
+                for msg in degraded:
+                    sys.stderr.write("bench: PRE-FLIGHT FAILED on the peer-mapped data plane: %s\n" % msg)
+                sys.stderr.write("bench: DEGRADED: the line is quoted on the communicator's data plane, which passed\n")
+                provisional["degraded"] = {"why": "the peer-mapped data plane failed its pre-flight; nothing was timed on it",
+                                           "value_is_quoted_on": provisional["config"]["data_plane"], "problems": degraded}
+                provisional["preflight"] = {"ok": False, "checks": checks, "problems": degraded,
+                                            "ok_on_the_plane_value_is_quoted_on": True}
+                print(json.dumps(provisional), flush=True)
+            L.sb_comm_data_plane(0)
+            barrier()
+            prob.free()
+            L.sb_comm_finalize()
+            dist.destroy_process_group()
+            return
+
+        modes = [default] + ([0] if default != 0 else [])
+        res = measure(prob, modes, clean_all=(world == 1) or args.all_clean)
         # third leg, peer-mapped halo only: the halo push inside the SpMV launch (one launch fewer per body).  Which
         # variant is faster can only be decided with one rank per GPU, i.e. by this very run on a real node; validated by
         # its own pre-flight, and a failure here does not invalidate `value` (the variant is simply reported as failed).
@@ -938,10 +1072,13 @@ def main():
         if os.environ.get("SB_BENCH_RANK_PROCESS"):
             sys.stderr.write("bench: rank process with WORLD_SIZE=%d but --gpus %d\n" % (world, args.gpus))
             return 2
-        return spawn_ranks(args.gpus, sys.argv[1:])  # before any HIP call; this process stays off the GPU
+        return supervise(list(range(args.gpus)), args.gpus, sys.argv[1:], True)  # before any HIP call; this process stays off the GPU
     if args.gpus == 1 and world > 1:
         sys.stderr.write("bench: --gpus 1 but WORLD_SIZE=%d\n" % world)
         return 2
+    if world > 1 and not os.environ.get("SB_BENCH_RANK_PROCESS"):
+        # a rank process started by torch.distributed.run: supervise ONE worker (this process stays off the GPU)
+        return supervise([int(os.environ.get("RANK", "0"))], world, sys.argv[1:], False)
     run_rank(args)
     return 0
 

@@ -459,6 +459,15 @@ static void halo_p2p_setup(sb_halo* h)
   bool on = agree(ok);
   if (!on && ok) snprintf(why, sizeof why, "another rank could not export / map a staging area");
   if (on) {
+    // TEST HOOK (bench.py's degraded completion, tests/test_gpu_bench.py): SB_TEST_CORRUPT_P2P_HALO=r makes rank r's
+    // peer-mapped push deliver its first two values in each other's places -- wrong on the peer-mapped plane ONLY (the
+    // communicator's send / recv does not use the slot list; the self-test below sends one value in every slot)
+    if (const char* bad = getenv("SB_TEST_CORRUPT_P2P_HALO")) {
+      if (atoi(bad) == g.rank && h->totalSend >= 2 && dest[0] == dest[1]) {
+        std::swap(slot[0], slot[1]);
+        fprintf(stderr, "sbhip: rank %d: SB_TEST_CORRUPT_P2P_HALO is set: the peer-mapped push swaps its first two values (test hook)\n", g.rank);
+      }
+    }
     h->slot = (uint32_t*)upload(slot.data(), slot.size() * sizeof(uint32_t));
     h->dest = (uint8_t*)upload(dest.data(), dest.size());
     h->done = (unsigned int*)sb_malloc(sizeof(unsigned int));

@@ -91,6 +91,56 @@ def test_a_rank_that_dies_ends_the_run_at_once_with_its_exit_code(gpu):
     assert d is None and "rank 2 exited with code 7" in err and time.time() - t0 < 120
 
 
+def _peer_mapped_up(d):
+    return d["config"].get("dot_allreduce") == "in_kernel_peer_mapped" or "rccl_only" in d and "value" in d["rccl_only"]
+
+
+def test_a_peer_mapped_plane_that_delivers_wrong_values_degrades_to_the_validated_plane(gpu):
+    """first contact with real links must yield a line if ANY validated plane works: SB_TEST_CORRUPT_P2P_HALO=1 makes rank
+    1's peer-mapped push swap two values (the communicator's plane is untouched).  The communicator's plane passes its
+    pre-flight and is timed first; the peer-mapped plane fails its own: the line is quoted on the former, says so, exit 0."""
+    ok, _ = run_bench("--gpus", "2", "--transport", "host", "--steps", "10", "--n", "32", "--no-cpu", "--no-push-inside-leg")
+    if ok["config"]["halo_exchange"] != "peer_mapped_push_pull":
+        pytest.skip("the peer-mapped halo did not come up on this box: nothing to degrade from")
+    d, err = run_bench("--gpus", "2", "--transport", "host", "--steps", "10", "--n", "32", "--no-cpu",
+                       env={"SB_TEST_CORRUPT_P2P_HALO": "1"})
+    assert d["value"] > 0 and d["config"]["data_plane"] == "host_staged_gloo data plane"
+    dg = d["degraded"]
+    assert "peer-mapped data plane failed its pre-flight" in dg["why"] and dg["problems"] and "DEGRADED" in err
+    pf = d["preflight"]
+    assert pf["ok"] is False and pf["ok_on_the_plane_value_is_quoted_on"] is True
+    assert [c["ok"] for c in pf["checks"]] == [True, False]  # communicator's plane, then the peer-mapped one
+    # (the rate is the communicator plane's: what the healthy run reports as rccl_only, within rehearsal noise)
+    assert 0.3 < d["value"] / ok["rccl_only"]["value"] < 3.0
+
+
+def test_a_crash_in_the_peer_mapped_legs_still_yields_the_validated_line(gpu):
+    d, err = run_bench("--gpus", "2", "--transport", "host", "--steps", "10", "--n", "32", "--no-cpu",
+                       env={"SB_BENCH_TEST_DIE_AFTER_CHECKPOINT": "1"})
+    if "degraded" not in d:
+        pytest.skip("one data plane only on this box (no checkpoint): %s" % d["config"].get("dot_allreduce_reason"))
+    assert d["value"] > 0 and d["preflight"]["ok"] and d["config"]["data_plane"] == "host_staged_gloo data plane"
+    assert "rank 1 exited with code 9" in d["degraded"]["why"] and d["degraded"]["exit_codes"]["1"] == 9
+
+
+def test_as_the_driver_launches_it_under_torch_distributed_run(gpu):
+    """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`: every rank process supervises one worker"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport",
+                          "host", "--steps", "10", "--warmup", "3", "--grid", "32", "--no-cpu"], stdout=subprocess.PIPE,  # ("--n" is an ambiguous prefix for torchrun's own parser)
+                         stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["preflight"]["ok"] and "degraded" not in d and len(d["per_rank"]["ms_per_step"]) == 2
+
+
 def test_five_ranks_next_to_the_test_process(gpu):
     """the pool allows 6 processes per GPU and this test process holds one of them: 5 ranks here; N = 6 is rehearsed from the
     command line (profiles/r03_bench_rehearsal_n6.json), where bench.py's parent stays off the GPU"""
