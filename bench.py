@@ -463,8 +463,8 @@ def check_history(label, rr, pap, n, world, key, goldens):
 # ------------------------------------------------------------------------------------------------
 # one rank
 # ------------------------------------------------------------------------------------------------
-def kernel_name(fmt, mode):
-    native = "spmv_crs_stream" if fmt == "crs" else "spmv_scs64"
+def kernel_name(fmt, mode, crs_split=True):
+    native = ("spmv_crs_split" if crs_split else "spmv_crs_stream") if fmt == "crs" else "spmv_scs64"
     return {0: native, 1: "spmv_scs64_packed", 2: "spmv_scs64_lds", 3: "spmv_scs64_pat", 5: "spmv_scs64_pat_masked"}[mode]
 
 
@@ -582,7 +582,7 @@ def run_rank(args):
             if own:
                 with quiet_stdout():
                     pr = hostapi.Problem("generate", nn, nn, nn, fmt=args.fmt, Cc=args.C, sigma=args.sigma, rank=rank, size=world)
-            cg = hostapi.CG(pr, fused=args.fused, graph=False, fuse_p=args.fuse_p)
+            cg = hostapi.CG(pr, fused=args.fused, graph=False, fuse_p=args.fuse_p, fuse_alpha=args.fuse_alpha)
             cg.solve(PREFLIGHT_ITERS, 0.0)
             rr, pap = cg.history()
             cg.free()
@@ -623,7 +623,7 @@ def run_rank(args):
     def measure(prob, modes, clean_all=False, phases=True):
         """timed passes on one resident matrix.  modes: kernel modes to time with per-launch events; the
         first is the one `value` is quoted on.  Every mode gets a clean pass (no events) when clean_all."""
-        cg = hostapi.CG(prob, fused=args.fused, graph=bool(args.graph), fuse_p=args.fuse_p)
+        cg = hostapi.CG(prob, fused=args.fused, graph=bool(args.graph), fuse_p=args.fuse_p, fuse_alpha=args.fuse_alpha)
         nonlocal vphase, launches, collectives, fuse_p
         vphase, launches, collectives, fuse_p = cg.vector_phase(), cg.launches_per_body(), cg.collectives_per_body(), cg.fuse_p()
 
@@ -800,7 +800,7 @@ def run_rank(args):
                 res_inside = measure(prob, [default])
                 launches_inside = launches
             L.sb_comm_halo_push_inside(0)
-            cg_tmp = hostapi.CG(prob, fused=args.fused, fuse_p=args.fuse_p)
+            cg_tmp = hostapi.CG(prob, fused=args.fused, fuse_p=args.fuse_p, fuse_alpha=args.fuse_alpha)
             launches, vphase, collectives, fuse_p = cg_tmp.launches_per_body(), cg_tmp.vector_phase(), cg_tmp.collectives_per_body(), cg_tmp.fuse_p()
             cg_tmp.free()
         rccl = (ctypes.c_int * 3)()
@@ -814,7 +814,7 @@ def run_rank(args):
         if rank == 0:
             d = res[default]
             it_s = K / d["t_clean"]
-            kern = kernel_name(args.fmt, default)
+            kern = kernel_name(args.fmt, default, bool(L.sb_matrix_crs_kernel(prob.matrix)))
             if d["fuse_p"]:
                 # the SpMV launch also takes the p update: + r and p_old read, p_new written, x read and written = 40 B/row,
                 # the same 64 B/row of vector traffic per iteration as with the separate kernel
@@ -893,7 +893,7 @@ def run_rank(args):
                     d["moved"] / 1e6, d["alg"] / 1e6) if default > 0 else "kernel streams the reference layout: bytes = SURVEY 8d")
             if default != 0 and 0 in res:
                 r0 = res[0]
-                k0 = kernel_name(args.fmt, 0)
+                k0 = kernel_name(args.fmt, 0, bool(L.sb_matrix_crs_kernel(prob.matrix)))
                 tr0 = pmc_traffic(workload, k0, version) if world == 1 else (None, None, "N > 1")
                 blk = roofline_block(k0, r0["moved"], r0["alg"], r0["spmv_us"], r0["launches"], *tr0)
                 blk["cg_iterations_per_s_with_events"] = (world * K / r0["t_ev"]) if r0["t_ev"] else None
@@ -961,7 +961,7 @@ def run_rank(args):
                 for fmt, sigma in specs:
                     with quiet_stdout():
                         pr = hostapi.Problem("irregular", 24, 24, 24, fmt=fmt, Cc=64, sigma=sigma)
-                    cgp = hostapi.CG(pr, fused=args.fused, fuse_p=args.fuse_p)
+                    cgp = hostapi.CG(pr, fused=args.fused, fuse_p=args.fuse_p, fuse_alpha=args.fuse_alpha)
                     kk = cgp.solve(gold["itermax"], 0.0)
                     rr, pap = cgp.history()
                     cgp.free()
@@ -987,7 +987,7 @@ def run_rank(args):
             d = res[default]
             name = "crs" if fmt == "crs" else "scs_C64_sigma%d" % sigma
             workload = "irregular_fe_%d^3_nodes_%s" % (n, name)
-            kern = kernel_name(fmt, default)
+            kern = kernel_name(fmt, default, bool(L.sb_matrix_crs_kernel(prob.matrix)))
             tr = pmc_traffic(workload, kern, version)
             # (a native CRS kernel without the fused p.Ap adds a dot pass over p and Ap: 16 B/row)
             dot_pass = bool(d["phases"] and "dot_pass" in d["phases"])
@@ -1044,6 +1044,8 @@ def main():
                          "2 / 3 the measured-slower alternatives (lab builds only)")
     ap.add_argument("--fuse-p", type=int, default=-1, help="the p update inside the SpMV launch where the matrix allows it: 1 / 0, "
                                                            "-1 (default): the library's choice")
+    ap.add_argument("--fuse-alpha", type=int, default=-1, help="the alpha step inside the r update's launch (one rank): 1 / 0, -1 (default): "
+                                                               "the library's choice")
     ap.add_argument("--pack-mode", type=int, default=-1,
                     help="SpMV stream: 0 reference layout, 5 masked row programs + LDS x-window where the matrix qualifies "
                          "(default -1: the library's choice); 1-3 intermediate forms (lab builds only)")

@@ -104,6 +104,10 @@ int sb_matrix_pack_level(const sb_matrix* m);
  * padding is not added (exactly the CRS loop's sums); built when the matrix has repeating row patterns. */
 void sb_matrix_use_packed(sb_matrix* m, int mode);
 int sb_matrix_packed_mode(const sb_matrix* m);
+/* which native CRS kernel streams the reference's arrays (pack mode 0): 1 spmv_crs_split -- equal windows of nonzeros, the
+ * default where no row is longer than 1025 --, 0 spmv_crs_stream (row blocks; SB_CRS_KERNEL=stream forces it).  Both:
+ * src/matrix-CRS.c:46-65, same bits. */
+int sb_matrix_crs_kernel(const sb_matrix* m);
 uint32_t sb_matrix_lds_window(const sb_matrix* m); /* doubles per workgroup, 0 if not built */
 uint32_t sb_matrix_pattern_classes(const sb_matrix* m); /* pattern tables built (mode 3), 0 if none */
 /* mode 3, level 5: distinct shared row patterns; *uniformChunks = chunks stored as one row
@@ -264,6 +268,10 @@ int sb_cg_collectives_per_body(sb_cg* s);
  * on = 1 / 0 selects / deselects it, -1 = default (SB_FUSE_P, else the library's choice).  sb_cg_fuse_p: what the loop will do. */
 void sb_cg_set_fuse_p(sb_cg* s, int on);
 int sb_cg_fuse_p(sb_cg* s);
+/* The alpha step (src/CGSolver.c:124-126) inside the r update's launch: every workgroup of the r update reduces the p.Ap
+ * values itself in the canonical order (identical bits everywhere), workgroup 0 records the step -- one launch fewer per loop
+ * body on one rank (sb_cg_launches_per_body tells).  on = 1 / 0, -1 = default (SB_FUSE_ALPHA, else on).  Same bits. */
+void sb_cg_set_fuse_alpha(sb_cg* s, int on);
 void sb_cg_set_graph(sb_cg* s, int use_graph);
 /* Runs solveCG's whole loop without host synchronisation; returns k exactly as
  * the reference does (src/CGSolver.c:140).  Blocking. */

@@ -28,11 +28,11 @@ SYMBOLS = [
     "sb_comm_allgather_bytes", "sb_comm_alltoallv_ints", "sb_comm_barrier", "sb_cg_loop_ms",
     "sb_cg_spmv_timing", "sb_cg_spmv_ms", "sb_cg_counters", "sb_debug_stream_read_gbs",
     "sb_matrix_pack_level", "sb_set_external_ids", "sb_spmv_native_dot", "sb_matrix_use_packed", "sb_matrix_stream_bytes",
-    "sb_matrix_packed_mode", "sb_matrix_lds_window", "sb_matrix_pattern_classes", "sb_matrix_row_patterns", "sb_matrix_row_programs", "sb_comm_p2p_handle", "sb_comm_p2p_open", "sb_comm_p2p_enabled", "sb_halo_p2p_enabled", "sb_cg_start", "sb_cg_finish", "sb_cg_vector_phase", "sb_cg_launches_per_body",
+    "sb_matrix_packed_mode", "sb_matrix_crs_kernel", "sb_matrix_lds_window", "sb_matrix_pattern_classes", "sb_matrix_row_patterns", "sb_matrix_row_programs", "sb_comm_p2p_handle", "sb_comm_p2p_open", "sb_comm_p2p_enabled", "sb_halo_p2p_enabled", "sb_cg_start", "sb_cg_finish", "sb_cg_vector_phase", "sb_cg_launches_per_body",
     "sb_comm_init_transport", "sb_comm_p2p_reason", "sb_halo_p2p_reason",
     "sb_comm_data_plane", "sb_comm_data_plane_selected", "sb_comm_rccl_info", "sb_cg_phase_timing", "sb_cg_phase_ms",
     "sb_comm_halo_push_inside", "sb_lab_build", "sb_cg_collectives_per_body",
-    "sb_cg_set_fuse_p", "sb_cg_fuse_p",
+    "sb_cg_set_fuse_p", "sb_cg_fuse_p", "sb_cg_set_fuse_alpha",
 ]
 
 _lib = None
@@ -121,6 +121,7 @@ def load():
         "sb_spmv_native_dot": (C.c_int, [vp, vp, vp, vp]),
         "sb_matrix_stream_bytes": (C.c_double, [vp]),
         "sb_matrix_packed_mode": (C.c_int, [vp]),
+        "sb_matrix_crs_kernel": (C.c_int, [vp]),
         "sb_matrix_lds_window": (C.c_uint32, [vp]),
         "sb_matrix_pattern_classes": (C.c_uint32, [vp]),
         "sb_matrix_row_patterns": (C.c_uint32, [vp, C.POINTER(C.c_uint32)]),
@@ -143,6 +144,7 @@ def load():
         "sb_cg_collectives_per_body": (C.c_int, [vp]),
         "sb_cg_set_fuse_p": (None, [vp, C.c_int]),
         "sb_cg_fuse_p": (C.c_int, [vp]),
+        "sb_cg_set_fuse_alpha": (None, [vp, C.c_int]),
         "sb_comm_rccl_info": (C.c_int, [C.POINTER(C.c_int)]),
         "sb_cg_phase_timing": (None, [vp, C.c_int]),
         "sb_cg_phase_ms": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

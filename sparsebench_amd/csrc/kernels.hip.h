@@ -400,6 +400,67 @@ __global__ __launch_bounds__(CRS_THREADS) void spmv_crs_stream(
   }
 }
 
+// The same product with the nonzeros cut into EQUAL windows (the default where no row is longer than CRS_SPLIT_MAXROW):
+// tile lb owns the rows that START in nonzeros [lb T, (lb + 1) T) and streams the fixed window [lb T, lb T + 2048), which
+// covers them to the end of the last one (T <= 2049 - longest row, a multiple of 64; the first few elements may belong to
+// the previous tile's last row: multiplied, never summed).  What this buys is the dependence chain: the window is known
+// from blockIdx alone, so the 16 stream loads of a thread leave at kernel entry together with the tile's row range
+// (tileRow: first row starting at or behind lb T, cut on the host), the gathers and the thread's row extent follow as
+// the second round trip, then LDS and the in-order sums -- two dependent round trips where spmv_crs_stream has four
+// (row block -> rowPtr of its ends -> stream -> gather), all tiles the same size.  Row sums are the same left-to-right
+// adds of the same products: same bits.  A tile may hold more than 256 rows (short or empty rows): threads loop.
+// Measured (one box, stand-alone / inside CG): HPCG 128^3 130.0 / 141.9 us against the row-block kernel's 139.5 / 152 us;
+// irregular stand-in 201.8 against 213.1 us (tools/crs_ab.py).  Tiles of 3072 / 4096 nonzeros (6 / 5 workgroups per CU):
+// 127.3 / 141.2 us against 124.7 us with 2048 on the same box -- kept at 2048.
+constexpr uint32_t CRS_SPLIT_MAXROW = 1025;
+__global__ __launch_bounds__(CRS_THREADS) void spmv_crs_split(
+    const uint32_t* __restrict__ tileRow, const uint32_t* __restrict__ rowPtr,
+    const uint32_t* __restrict__ colInd, const double* __restrict__ val,
+    const double* __restrict__ x, double* __restrict__ y, uint32_t nTiles, uint32_t T, uint32_t nnz,
+    uint32_t blocksPerXcd, const int* __restrict__ stop)
+{
+  __shared__ double prod[CRS_TILE];
+  const uint32_t lb = xcd_block(blockIdx.x, blocksPerXcd);
+  if (lb >= nTiles) return;
+  const uint32_t base = lb * T, t = threadIdx.x;
+  // a thread takes PAIRS of neighbouring nonzeros (16 B of val, 8 B of colInd per load: half the vector-memory instructions
+  // of an element per load; base is a multiple of 64 elements, the arrays end in 64 zeroed elements of slack)
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+  constexpr int PAIRS = CRS_BATCH / 2;
+  dbl2 v[PAIRS], xv[PAIRS];
+  uint2v c[PAIRS];
+#pragma unroll
+  for (int u = 0; u < PAIRS; u++) {
+    const uint32_t k = base + 2u * t + (uint32_t)u * 2u * CRS_THREADS;
+    v[u] = dbl2{ 0.0, 0.0 }, c[u] = uint2v{ 0u, 0u };
+    if (k < nnz) v[u] = stream_load(reinterpret_cast<const dbl2*>(val + k)), c[u] = stream_load(reinterpret_cast<const uint2v*>(colInd + k));
+  }
+  const int stopped = stop ? *stop : 0;
+  const uint32_t r0 = tileRow[lb], r1 = tileRow[lb + 1];
+  if (stopped) return;
+#pragma unroll
+  for (int u = 0; u < PAIRS; u++) xv[u] = dbl2{ x[c[u].x], x[c[u].y] };
+  uint32_t r = r0 + t, a = 0, b = 0;
+  if (r < r1) a = rowPtr[r] - base, b = rowPtr[r + 1] - base;
+#pragma unroll
+  for (int u = 0; u < PAIRS; u++)
+    *reinterpret_cast<dbl2*>(&prod[2u * t + (uint32_t)u * 2u * CRS_THREADS]) = dbl2{ v[u].x * xv[u].x, v[u].y * xv[u].y };
+  __syncthreads();
+  while (r < r1) {
+    double sum = 0.0;
+    uint32_t k = a;
+    for (; k + 4u <= b; k += 4u) { // four LDS reads in flight, then the four adds in order
+      const double d0 = prod[k], d1 = prod[k + 1u], d2 = prod[k + 2u], d3 = prod[k + 3u];
+      sum = (((sum + d0) + d1) + d2) + d3;
+    }
+    for (; k < b; k++) sum = sum + prod[k];
+    y[r] = sum;
+    r += CRS_THREADS;
+    if (r < r1) a = rowPtr[r] - base, b = rowPtr[r + 1] - base;
+  }
+}
+
 // =============================================================================
 // BLAS-1
 // =============================================================================
@@ -593,8 +654,17 @@ __global__ __launch_bounds__(256) void dot_spans_k(uint32_t n, const double* a, 
 // scalar step that follows reads n/256 doubles instead of n/64 (reduce_final_1024, l1).  The first group's loads go
 // in flight together with the stop flag / alpha instead of behind them.  Same arithmetic, same order, same bits as
 // a per-span r update followed by level1().
+//
+// ALPHA (one rank, 1024-thread workgroups, the p.Ap producer emits level-1 values): the alpha step rides in this launch --
+// EVERY workgroup reduces the m level-1 values of p.Ap itself (reduce_final_1024: the canonical order, so all of them
+// hold the same bits), divides, and goes on; workgroup 0 also records the step in the control block (cg_apply<2>).  Nobody
+// waits for anybody -- unlike the lead kernels of `fused = 3`, where workgroup 0 published and the others polled --, the
+// price is m * 8 bytes of L2 reads per workgroup (64 KB at 128^3, 512 workgroups) behind the first group's r / Ap loads,
+// which are already in flight.  One launch and its boundary fewer per loop body; same operations, same order, same bits.
+template <bool ALPHA>
 __global__ __launch_bounds__(1024) void cg_update_r_k(uint32_t n, const double* __restrict__ Ap, double* r,
-    const CgScalars* __restrict__ S, double* __restrict__ l1out, const int* __restrict__ stop)
+    CgScalars* S, double* __restrict__ l1out, const int* stop, uint32_t m, const double* __restrict__ pApL1,
+    double* __restrict__ rr_hist, double* __restrict__ pAp_hist)
 {
   const uint32_t lane    = threadIdx.x & 63u;
   const uint32_t nGroups = (n + 255u) >> 8;
@@ -608,8 +678,22 @@ __global__ __launch_bounds__(1024) void cg_update_r_k(uint32_t n, const double* 
     r0 = *reinterpret_cast<const double2*>(r + e0), a0 = *reinterpret_cast<const double2*>(Ap + e0);
     r1 = *reinterpret_cast<const double2*>(r + e1), a1 = *reinterpret_cast<const double2*>(Ap + e1);
   }
-  if (stop && *stop) return;
-  const double nalpha = -S->alpha;
+  double nalpha;
+  if (ALPHA) {
+    __shared__ double lds16[16];
+    const bool recorder = blockIdx.x == 0 && threadIdx.x == 0;
+    CgScalars in;
+    if (recorder) in = *S; // (prefetched next to the partials; only the recorder needs all of it)
+    const int stopped  = S->stop;
+    const double rr    = S->rr;
+    const double total = reduce_final_1024(m, pApL1, lds16, 1);
+    if (stopped) return;
+    nalpha = -(rr / total); // (= cg_apply<2>'s neg_alpha: -(in.rr / total))
+    if (recorder) cg_apply<2>(S, in, total, rr_hist, pAp_hist, 0);
+  } else {
+    if (stop && *stop) return;
+    nalpha = -S->alpha;
+  }
   auto combine = [&](double t0, double t1) { // halves of t0: q0, q1; of t1: q2, q3
     const double q0 = lane_value<0>(t0), q1 = lane_value<32>(t0), q2 = lane_value<0>(t1), q3 = lane_value<32>(t1);
     return ((q0 + q1) + q2) + q3;

@@ -8,6 +8,7 @@
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -188,6 +189,8 @@ struct sb_matrix {
   // CRS
   uint32_t *rowPtr = nullptr, *rowBlocks = nullptr;
   uint32_t nRowBlocks = 0;
+  uint32_t* tileRow = nullptr; // spmv_crs_split: first row starting at or behind nonzero lb * crsT (NULL: a row is too long)
+  uint32_t nCrsTiles = 0, crsT = 0;
   // SCS
   uint32_t C = 0, sigma = 0, nChunks = 0, nElems = 0, nrPadded = 0;
   uint32_t *chunkPtr = nullptr, *chunkLens = nullptr;
@@ -278,6 +281,7 @@ struct sb_cg {
   double* pbuf[2] = { nullptr, nullptr };
   int fusepPlan = -1; // 1: the loop uses spmv_prog_fusep, 0: not, -1: not decided yet
   int fusepWant = -1; // sb_cg_set_fuse_p: 1 / 0, -1: SB_FUSE_P or the library default
+  int fuseAlphaWant = -1; // sb_cg_set_fuse_alpha: 1 / 0, -1: SB_FUSE_ALPHA or the library default (on)
   CgScalars* S;
   double* partials;
   uint32_t nPartials;

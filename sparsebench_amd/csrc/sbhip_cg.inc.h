@@ -172,6 +172,7 @@ int sb_cg_vector_phase(sb_cg* s) { return vphase_plan(s) ? s->vSP : 0; }
 
 template <int MODE> static void scalar_launch(sb_cg* s, int defer_x, const double* q, int l1 = 0);
 static int pAp_is_level1(const sb_cg* s);
+static bool fusealpha_plan(sb_cg* s, int l1, uint32_t vb);
 
 #ifdef SB_LAB
 
@@ -211,7 +212,8 @@ static bool fusep_plan(sb_cg* s)
 // themselves are counted by sb_cg_collectives_per_body.
 int sb_cg_launches_per_body(sb_cg* s)
 {
-  const int base = vphase_plan(s) ? 2 : lead_plan(s) ? 3 : fusep_plan(s) ? 4 : s->fused ? 5 : 0;
+  int base = vphase_plan(s) ? 2 : lead_plan(s) ? 3 : fusep_plan(s) ? 4 : s->fused ? 5 : 0;
+  if (base >= 4 && fusealpha_plan(s, fusep_plan(s) ? 1 : pAp_is_level1(s), 1024u)) base -= 1; // (alpha step inside the r update)
   if (!multi_rank() || base == 0) return base;
   int n = base;
   if (s->halo) {
@@ -395,6 +397,46 @@ template <int MODE> static void scalar_launch(sb_cg* s, int defer_x, const doubl
 // 1: the SpMV's fused dot wrote LEVEL-1 values of p.Ap (one per 256 rows), 0: level-0 partials (dot pass, lab kernels)
 static int pAp_is_level1(const sb_cg* s) { return spmv_can_fuse_dot(s) && spmv_dot_kind(s->A) == 2 ? 1 : 0; }
 
+// The alpha step inside the r update's launch (cg_update_r_k<true>: every workgroup reduces the p.Ap values itself):
+// one rank (on several the step carries the all-reduce), level-1 values from the producer, 1024-thread workgroups.
+// SB_FUSE_ALPHA=0 / sb_cg_set_fuse_alpha(s, 0): the separate scalar launch.
+static bool fusealpha_plan(sb_cg* s, int l1, uint32_t vb)
+{
+  if (multi_rank() || !s->fused || !l1 || vb != 1024u || vphase_plan(s) || lead_plan(s)) return false;
+  static const int env = getenv("SB_FUSE_ALPHA") ? atoi(getenv("SB_FUSE_ALPHA")) != 0 : -1;
+  return s->fuseAlphaWant >= 0 ? s->fuseAlphaWant != 0 : env >= 0 ? env != 0 : true;
+}
+void sb_cg_set_fuse_alpha(sb_cg* s, int on) { s->fuseAlphaWant = on < 0 ? -1 : on != 0; }
+
+// alpha step (src/CGSolver.c:124-126) and r -= alpha Ap + the r.r values of the next body (:128, :112): two launches, or one
+static void alpha_and_r_update(sb_cg* s, int l1, uint32_t capV, uint32_t vb, const int* stop)
+{
+  const uint32_t n = s->nr;
+  const dim3 grid(std::max(1u, std::min(capV, (((n + 255u) >> 8) + vb / 64 - 1) / (vb / 64))));
+  if (fusealpha_plan(s, l1, vb)) {
+    // one workgroup per CU (the separate r update runs two): every workgroup reads all m values, so half the workgroups is half
+    // that traffic -- 128^3, same box, alternating: 41.6 / 42.1 us per iteration against 42.4 / 42.7 with two (and 43.8 / 44.2
+    // with the separate alpha launch)
+    static const uint32_t perCu = getenv("SB_ALPHA_WG_PER_CU") ? (uint32_t)std::max(1, atoi(getenv("SB_ALPHA_WG_PER_CU"))) : 1u;
+    const dim3 gridA(std::max(1u, std::min((uint32_t)g.prop.multiProcessorCount * perCu, grid.x)));
+    hipLaunchKernelGGL(cg_update_r_k<true>, gridA, dim3(vb), 0, g.stream, n, s->Ap, s->r, s->S, s->partials2, stop, s->nPartials,
+        (const double*)s->partials, s->rr_hist, s->pAp_hist);
+    HIP_CHECK(hipGetLastError());
+    mark(s, R_DDOT);
+    mark(s, R_WAXPBY);
+    phase_mark(s, PH_R_UPDATE);
+    return;
+  }
+  scalar_launch<2>(s, 0, nullptr, l1);
+  mark(s, R_DDOT);
+  phase_mark(s, PH_ALPHA);
+  hipLaunchKernelGGL(cg_update_r_k<false>, grid, dim3(vb), 0, g.stream, n, s->Ap, s->r, s->S, s->partials2, stop, 0u,
+      (const double*)nullptr, (double*)nullptr, (double*)nullptr);
+  HIP_CHECK(hipGetLastError());
+  mark(s, R_WAXPBY);
+  phase_mark(s, PH_R_UPDATE);
+}
+
 static void spmv_event(sb_cg* s)
 {
   if (!s->spmvTiming) return;
@@ -406,19 +448,47 @@ static void spmv_event(sb_cg* s)
   HIP_CHECK(hipEventRecord(s->spmvEv[s->spmvEvUsed++], g.stream));
 }
 
+// the SpMV launch that follows is the one to time: hand its launch site a pair of events (sbhip_launch.inc.h)
+// (SB_SPMV_TIMING=record: bracket the launch with hipEventRecord instead, as rounds 1-3 did -- for comparison)
+static bool spmv_time_begin(sb_cg* s)
+{
+  if (!s->spmvTiming) return false;
+  static const bool record = getenv("SB_SPMV_TIMING") && strcmp(getenv("SB_SPMV_TIMING"), "record") == 0;
+  if (record) {
+    spmv_event(s);
+    return true;
+  }
+  while (s->spmvEv.size() < s->spmvEvUsed + 2) {
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreate(&e));
+    s->spmvEv.push_back(e);
+  }
+  g_spmvEvA = s->spmvEv[s->spmvEvUsed], g_spmvEvB = s->spmvEv[s->spmvEvUsed + 1];
+  s->spmvEvUsed += 2;
+  return true;
+}
+static void spmv_time_end(sb_cg* s)
+{
+  if (!s->spmvTiming) return;
+  if (g_spmvEvA) g_spmvEvA = g_spmvEvB = nullptr;
+  else spmv_event(s);
+}
+
 // Ap = A p and the level-0 partials of p.Ap (src/CGSolver.c:123-125): fused into the SpMV epilogue
 // where the kernel is wave-per-chunk, otherwise SpMV then a dot pass
 static void spmv_and_pAp(sb_cg* s, const int* stop)
 {
   const uint32_t n = s->nr;
   if (spmv_can_fuse_dot(s)) {
+    spmv_time_begin(s);
     launch_spmv(s->A, s->p, s->Ap, s->partials, stop);
-    spmv_event(s);
+    spmv_time_end(s);
     mark(s, R_SPMVM);
     phase_mark(s, PH_SPMV);
   } else {
+    spmv_time_begin(s);
     launch_spmv(s->A, s->p, s->Ap, nullptr, stop);
-    spmv_event(s);
+    spmv_time_end(s);
     mark(s, R_SPMVM);
     phase_mark(s, PH_SPMV);
     launch_dot_spans(0, n, s->p, s->Ap, nullptr, nullptr, s->S, s->partials, stop);
@@ -464,17 +534,12 @@ static void loop_body(sb_cg* s, int k)
       hw.src = h->dSrcRank, hw.nsrc = h->indegree, hw.seq = seq, hw.err = h->err;
       hw.stopw = &s->S->stop, hw.timeoutTicks = h->push.timeoutTicks;
     }
-    spmv_event(s);
+    spmv_time_begin(s);
     launch_spmv_fusep(s->A, pold, s->r, pnew, s->x, s->Ap, s->S, which, s->partials, halo ? &hw : nullptr);
-    spmv_event(s);
+    spmv_time_end(s);
     phase_mark(s, PH_SPMV);
     s->p = pnew; // (host-side view: the newest p; cg_x_finalize picks the buffer of the last body that RAN from the device counters)
-    scalar_launch<2>(s, 0, nullptr, 1);
-    phase_mark(s, PH_ALPHA);
-    hipLaunchKernelGGL(cg_update_r_k, dim3(std::max(1u, std::min(capV, (((n + 255u) >> 8) + vb / 64 - 1) / (vb / 64)))), dim3(vb), 0, g.stream, n, s->Ap, s->r, s->S,
-        s->partials2, stop);
-    HIP_CHECK(hipGetLastError());
-    phase_mark(s, PH_R_UPDATE);
+    alpha_and_r_update(s, 1, capV, vb, stop);
     scalar_launch<1>(s, 1, s->partials2, 1);
     phase_mark(s, PH_BETA);
     return;
@@ -552,16 +617,15 @@ static void loop_body(sb_cg* s, int k)
     hw.ext   = reinterpret_cast<const double*>(h->stage + (h->seq & 1ull) * (size_t)h->externalCount);
     hw.src = h->dSrcRank, hw.nsrc = h->indegree, hw.seq = h->seq, hw.err = h->err;
     hw.stopw = &s->S->stop, hw.timeoutTicks = h->push.timeoutTicks;
-    spmv_event(s);
+    spmv_time_begin(s);
     launch_spmv(s->A, s->p, s->Ap, s->partials, stop, 0, nullptr, &hw);
-    spmv_event(s);
+    spmv_time_end(s);
     mark(s, R_SPMVM);
     phase_mark(s, PH_SPMV);
   } else {
     halo_exchange(s->halo, s->p, stop, nullptr, true); // :122
     mark(s, R_COMM);
     if (multi_rank() && s->halo) phase_mark(s, PH_HALO);
-    spmv_event(s);
     spmv_and_pAp(s, stop);
   }
   if (vphase_plan(s)) { // alpha | x, r update + r.r | beta, loop test | the next body's p update: one launch
@@ -574,20 +638,18 @@ static void loop_body(sb_cg* s, int k)
     phase_mark(s, PH_R_UPDATE);
     return;
   }
-  scalar_launch<2>(s, 0, nullptr, pAp_is_level1(s));
-  mark(s, R_DDOT);
-  phase_mark(s, PH_ALPHA);
-  if (s->fused) { // r -= alpha Ap (:128) + next r.r, beta, loop test; x += alpha p (:127) is owed
+  if (s->fused) { // alpha; r -= alpha Ap (:128) + next r.r, beta, loop test; x += alpha p (:127) is owed
     // (level-1 values of r.r into partials2: `partials` keeps the layout the p.Ap producers write)
-    hipLaunchKernelGGL(cg_update_r_k, dim3(std::max(1u, std::min(capV, (((n + 255u) >> 8) + vb / 64 - 1) / (vb / 64)))), dim3(vb), 0, g.stream, n, s->Ap, s->r, s->S,
-        s->partials2, stop);
-    HIP_CHECK(hipGetLastError());
-    mark(s, R_WAXPBY);
-    phase_mark(s, PH_R_UPDATE);
+    alpha_and_r_update(s, pAp_is_level1(s), capV, vb, stop);
     scalar_launch<1>(s, 1, s->partials2, 1);
     mark(s, R_DDOT);
     phase_mark(s, PH_BETA);
-  } else if (n) {
+    return;
+  }
+  scalar_launch<2>(s, 0, nullptr, pAp_is_level1(s));
+  mark(s, R_DDOT);
+  phase_mark(s, PH_ALPHA);
+  if (n) {
     const dim3 gridW(stream_grid(n / 2 + 1, 256)), blockW(256); // (the reference-shaped ops keep their 256-thread workgroups)
     hipLaunchKernelGGL(waxpby_sdev_k, gridW, blockW, 0, g.stream, n, s->x, &s->S->alpha, s->p, s->x, stop);
     hipLaunchKernelGGL(waxpby_sdev_k, gridW, blockW, 0, g.stream, n, s->r, &s->S->neg_alpha, s->Ap, s->r, stop);

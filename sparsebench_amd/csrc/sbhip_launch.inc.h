@@ -3,6 +3,17 @@
 // ===========================================================================
 // kernels
 // ===========================================================================
+// SpMV launch timing (sb_cg_spmv_timing; bench.py's roofline leg): while the CG loop has set a pair of events, the SpMV
+// launch below goes through hipExtLaunchKernelGGL, which stamps them with the BEGIN and END of that kernel's own
+// execution -- the launch duration rocprofv3 reports -- instead of bracketing the launch with hipEventRecord, which also
+// counts the gap to the previous kernel's end and the dispatch (~5-14 us on a kernel that follows a vector kernel).
+static hipEvent_t g_spmvEvA = nullptr, g_spmvEvB = nullptr;
+#define SB_SPMV_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                  \
+  do {                                                                                                           \
+    if (g_spmvEvA) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, g_spmvEvA, g_spmvEvB, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                    \
+  } while (0)
+
 static int g_scs_unroll = -1;
 static int g_scs_nt     = -1;
 static int g_scs_xcd    = 1;
@@ -35,8 +46,15 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
   } else if (m->fmt == 0) {
     if (dot) SB_FATAL("the native CRS kernel has no fused dot (its row blocks are not aligned to the 64-row groups of "
                       "the canonical dot; a kernel that is was measured slower, kernels.hip.h): sbhip_cg adds a dot pass");
+    if (m->tileRow) {
+      const uint32_t per = (m->nCrsTiles + 7) / 8;
+      SB_SPMV_LAUNCH(spmv_crs_split, dim3(per * 8), dim3(CRS_THREADS), 0, g.stream, m->tileRow, m->rowPtr, m->colInd, m->val, x, y,
+          m->nCrsTiles, m->crsT, m->nnz, per, stop);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     const uint32_t per = (m->nRowBlocks + 7) / 8;
-    hipLaunchKernelGGL(spmv_crs_stream, dim3(per * 8), dim3(CRS_THREADS), 0, g.stream, m->rowBlocks, m->rowPtr, m->colInd,
+    SB_SPMV_LAUNCH(spmv_crs_stream, dim3(per * 8), dim3(CRS_THREADS), 0, g.stream, m->rowBlocks, m->rowPtr, m->colInd,
         m->val, x, y, m->nRowBlocks, per, stop);
   } else if (m->C == 64) {
     if (g_scs_unroll < 0) {
@@ -56,7 +74,7 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
     } else if (m->usePacked == 2) {
       const size_t shmem = (256 + (size_t)m->ldsWindow) * sizeof(double);
 #define LDS_LAUNCH(DI, DO)                                                                                   \
-  hipLaunchKernelGGL((spmv_scs64_lds<DI, DO>), grid, block, shmem, g.stream, m->pmeta, m->pslots, m->pcodes, \
+  SB_SPMV_LAUNCH((spmv_scs64_lds<DI, DO>), grid, block, shmem, g.stream, m->pmeta, m->pslots, m->pcodes, \
       m->pdict, m->chunkPtr, m->val, m->tileSegPtr, m->tileSegs, x, y, m->nr, m->nChunks, per, m->padCol,    \
       dotPartials, stop)
       if (m->nDict > 0) {
@@ -69,7 +87,7 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
 #undef LDS_LAUNCH
     } else if (m->usePacked == 1) {
 #define PK_LAUNCH(DI, DO)                                                                                 \
-  hipLaunchKernelGGL((spmv_scs64_packed<DI, DO>), grid, block, 0, g.stream, m->pmeta, m->pidx, m->pcodes, \
+  SB_SPMV_LAUNCH((spmv_scs64_packed<DI, DO>), grid, block, 0, g.stream, m->pmeta, m->pidx, m->pcodes, \
       m->pdict, m->chunkPtr, m->val, x, y, m->nr, m->nChunks, per, m->padCol, dotPartials, stop)
       if (m->nDict > 0) {
         if (dot) PK_LAUNCH(true, true);
@@ -82,7 +100,7 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
 #endif // SB_LAB
     } else {
 #define SCS_LAUNCH(U, D, N)                                                                      \
-  hipLaunchKernelGGL((spmv_scs64<U, D, N>), grid, block, 0, g.stream, m->chunkPtr, m->chunkLens, \
+  SB_SPMV_LAUNCH((spmv_scs64<U, D, N>), grid, block, 0, g.stream, m->chunkPtr, m->chunkLens, \
       m->colInd, m->val, x, y, m->nr, m->nChunks, per, dotPartials, stop)
 #define SCS_PICK(U)                                                                           \
   do {                                                                                        \
@@ -105,7 +123,7 @@ static void launch_spmv(const sb_matrix* m, const double* x, double* y, double* 
     }
   } else {
     if (dot) SB_FATAL("fused dot is an SCS C=64 feature");
-    hipLaunchKernelGGL(spmv_scs_generic, dim3((m->nrPadded + 255) / 256), dim3(256), 0, g.stream,
+    SB_SPMV_LAUNCH(spmv_scs_generic, dim3((m->nrPadded + 255) / 256), dim3(256), 0, g.stream,
         m->chunkPtr, m->chunkLens, m->colInd, m->val, x, y, m->nr, m->nrPadded, m->C, stop);
   }
   HIP_CHECK(hipGetLastError());
@@ -132,7 +150,7 @@ static void launch_pat(const sb_matrix* pm, bool skipPad, bool masked, const dou
   const uint32_t* codes  = masked ? pm->mStream : pm->jcodes;
   const uint16_t* rbase  = masked ? reinterpret_cast<const uint16_t*>(pm->mRowBase) : pm->rowBase;
 #define PAT_LAUNCH(CP, DO, SK, HA, MA)                                                                                     \
-  hipLaunchKernelGGL((spmv_scs64_pat<CP, DO, SK, HA, MA>), pgrid, block, shmem, stream, hdrs, codes, rbase,                \
+  SB_SPMV_LAUNCH((spmv_scs64_pat<CP, DO, SK, HA, MA>), pgrid, block, shmem, stream, hdrs, codes, rbase,                \
       masked ? pm->mClassDict : pm->classDict, pm->rowPats, pm->excRows, pm->mProgs, pm->mSlotMap, pm->mMapStride,           \
       masked ? pm->mSegs : pm->patSegs, x, y, pm->nr, pm->nChunks, first, count, pper, pm->padCol, dictE, excE, dotPartials, \
       stop, hw)
@@ -194,7 +212,7 @@ static void launch_spmv_fusep(const sb_matrix* m, const double* pold, const doub
   const dim3 pgrid((g_scs_xcd ? pper * 8 : count) + (halo ? hw.nPush : 0u)), block(256);
   const size_t shmem = (16 + (size_t)pm->mWindow) * sizeof(double);
 #define FP_LAUNCH(CP, SK, HA, MP)                                                                                          \
-  hipLaunchKernelGGL((spmv_prog_fusep<CP, SK, HA, MP>), pgrid, block, shmem, g.stream, pm->mHdrs, pm->mRowBase, pm->mProgs,  \
+  SB_SPMV_LAUNCH((spmv_prog_fusep<CP, SK, HA, MP>), pgrid, block, shmem, g.stream, pm->mHdrs, pm->mRowBase, pm->mProgs,  \
       pm->mSlotMap, pm->mMapStride, pold, r, pnew, xsol, y, S, which, pm->nr, pm->nChunks, 0u, count, pper, pm->padCol, dotL1, hw)
 #define FP_PICK(CP, SK, HA)               \
   do {                                    \

@@ -38,6 +38,25 @@ sb_matrix* sb_crs_upload(uint32_t nr, uint32_t nc, const uint32_t* rowPtr, const
     m->nRowBlocks = (uint32_t)rb.size() - 1;
     m->rowBlocks  = (uint32_t*)upload(rb.data(), rb.size() * sizeof(uint32_t));
   }
+  // Equal nonzero windows of spmv_crs_split (kernels.hip.h) where the longest row allows it
+  {
+    uint32_t longest = 0;
+    for (uint32_t i = 0; i < nr; i++) longest = std::max(longest, rowPtr[i + 1] - rowPtr[i]);
+    const char* env = getenv("SB_CRS_KERNEL"); // "stream": keep the row-block kernel (A/B)
+    if (longest <= CRS_SPLIT_MAXROW && !(env && strcmp(env, "stream") == 0)) {
+      const uint32_t T = ((uint32_t)CRS_TILE + 1u - std::max(longest, 1u)) / 64u * 64u;
+      const uint32_t nTiles = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)m->nnz + T - 1) / T));
+      std::vector<uint32_t> tr((size_t)nTiles + 1);
+      uint32_t r = 0;
+      for (uint32_t lb = 0; lb < nTiles; lb++) {
+        while (r < nr && (uint64_t)rowPtr[r] < (uint64_t)lb * T) r++;
+        tr[lb] = r;
+      }
+      tr[nTiles]   = nr; // (rows behind the last nonzero -- empty ones -- belong to the last tile)
+      m->nCrsTiles = nTiles, m->crsT = T;
+      m->tileRow   = (uint32_t*)upload(tr.data(), tr.size() * sizeof(uint32_t));
+    }
+  }
   m->rowPtr     = (uint32_t*)upload(rowPtr, ((size_t)nr + 1) * sizeof(uint32_t));
   // (64 zeroed elements of slack behind the arrays)
   HIP_CHECK(hipMalloc(&m->colInd, ((size_t)m->nnz + 64) * sizeof(uint32_t)));
@@ -1145,7 +1164,7 @@ static void build_crs_mirror(sb_matrix* m, const uint32_t* rowPtr, const uint32_
 void sb_matrix_free(sb_matrix* m)
 {
   if (!m) return;
-  sb_free(m->rowPtr), sb_free(m->rowBlocks), sb_free(m->chunkPtr), sb_free(m->chunkLens);
+  sb_free(m->rowPtr), sb_free(m->rowBlocks), sb_free(m->tileRow), sb_free(m->chunkPtr), sb_free(m->chunkLens);
   sb_free(m->oldToNew), sb_free(m->newToOld), sb_free(m->colInd), sb_free(m->val);
   sb_free(m->pmeta), sb_free(m->pidx), sb_free(m->pcodes), sb_free(m->pdict);
   if (m->patSegs != m->tileSegs) sb_free(m->patSegs);
@@ -1175,6 +1194,7 @@ void sb_matrix_use_packed(sb_matrix* m, int mode)
 #endif
 }
 int sb_matrix_packed_mode(const sb_matrix* m) { return m->usePacked; }
+int sb_matrix_crs_kernel(const sb_matrix* m) { return m->fmt == 0 && m->tileRow ? 1 : 0; }
 // the matrix whose pattern levels serve m: m itself (SCS) or its private mirror (CRS)
 static const sb_matrix* pat_of(const sb_matrix* m) { return m->fmt == 0 && m->mirror ? m->mirror : m; }
 uint32_t sb_matrix_lds_window(const sb_matrix* m)

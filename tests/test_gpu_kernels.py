@@ -138,6 +138,37 @@ def test_spmv_ragged_random_and_long_rows(gpu):
             L.sb_matrix_free(m)
 
 
+def test_crs_equal_nonzero_windows_edge_cases(gpu):
+    """spmv_crs_split (tiles = equal windows of nonzeros; kernels.hip.h): more than 256 rows in a tile (short and empty rows:
+    threads loop), no nonzeros at all, empty rows behind the last nonzero, rows that end exactly on / start exactly at a window
+    boundary, the longest row the kernel takes (1025: T = 1024) and the first length it leaves to the row-block kernel"""
+    L = gpu
+    rng = np.random.default_rng(77)
+
+    def check(lens, nc, want_split):
+        lens = np.asarray(lens, dtype=np.int64)
+        rp = np.zeros(len(lens) + 1, dtype=np.uint32)
+        rp[1:] = np.cumsum(lens)
+        col = rng.integers(0, nc, size=int(rp[-1])).astype(np.uint32)
+        val = rng.standard_normal(int(rp[-1]))
+        g = po.GMatrix.from_csr(rp, col, val, nc=nc)
+        x = rng.standard_normal(nc)
+        m = upload_crs(L, g)
+        assert L.sb_matrix_crs_kernel(m) == (1 if want_split else 0), (len(lens), int(lens.max(initial=0)))
+        assert np.array_equal(gpu_spmv(L, m, x, g.nr), g.spmv(x)), (len(lens), int(lens.max(initial=0)))
+        L.sb_matrix_free(m)
+
+    check(rng.integers(0, 4, size=20000), 500, True)            # ~1400 rows per tile
+    check(np.zeros(3000), 10, True)                              # no nonzeros: one tile, 3000 empty rows
+    check(np.r_[rng.integers(1, 30, size=4000), np.zeros(700)], 4000, True)   # empty rows behind the last nonzero
+    check(np.r_[np.zeros(300), rng.integers(1, 30, size=4000)], 4000, True)   # ... and in front of the first
+    check(np.full(4096, 31), 4096, True)                         # T = 1984 = 64 rows of 31: rows end exactly on the boundaries
+    check(np.r_[np.full(64, 31), [0, 0, 0], np.full(640, 31)], 999, True)     # empty rows exactly at a boundary
+    check(np.r_[rng.integers(0, 9, size=900), [1025], rng.integers(0, 9, size=900)], 2000, True)
+    check(np.r_[rng.integers(0, 9, size=900), [1026], rng.integers(0, 9, size=900)], 2000, False)
+    check(np.full(9, 1025), 1500, True)                          # every row the longest
+
+
 def test_packed_stream_levels_and_wide_chunks(gpu):
     """the lossless compressed mirror: dictionary on/off, 16-bit and 32-bit (wide) chunks,
     padding marker, sigma > 1 (renumbered padding column), chunk widths 0..9 mod 4"""
