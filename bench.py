@@ -582,7 +582,7 @@ def run_rank(args):
             if own:
                 with quiet_stdout():
                     pr = hostapi.Problem("generate", nn, nn, nn, fmt=args.fmt, Cc=args.C, sigma=args.sigma, rank=rank, size=world)
-            cg = hostapi.CG(pr, fused=args.fused, graph=False, fuse_p=args.fuse_p, fuse_alpha=args.fuse_alpha)
+            cg = hostapi.CG(pr, fused=args.fused, graph=False, fuse_p=args.fuse_p, fuse_alpha=args.fuse_alpha, fuse_beta=args.fuse_beta)
             cg.solve(PREFLIGHT_ITERS, 0.0)
             rr, pap = cg.history()
             cg.free()
@@ -623,7 +623,7 @@ def run_rank(args):
     def measure(prob, modes, clean_all=False, phases=True):
         """timed passes on one resident matrix.  modes: kernel modes to time with per-launch events; the
         first is the one `value` is quoted on.  Every mode gets a clean pass (no events) when clean_all."""
-        cg = hostapi.CG(prob, fused=args.fused, graph=bool(args.graph), fuse_p=args.fuse_p, fuse_alpha=args.fuse_alpha)
+        cg = hostapi.CG(prob, fused=args.fused, graph=bool(args.graph), fuse_p=args.fuse_p, fuse_alpha=args.fuse_alpha, fuse_beta=args.fuse_beta)
         nonlocal vphase, launches, collectives, fuse_p
         vphase, launches, collectives, fuse_p = cg.vector_phase(), cg.launches_per_body(), cg.collectives_per_body(), cg.fuse_p()
 
@@ -800,7 +800,7 @@ def run_rank(args):
                 res_inside = measure(prob, [default])
                 launches_inside = launches
             L.sb_comm_halo_push_inside(0)
-            cg_tmp = hostapi.CG(prob, fused=args.fused, fuse_p=args.fuse_p, fuse_alpha=args.fuse_alpha)
+            cg_tmp = hostapi.CG(prob, fused=args.fused, fuse_p=args.fuse_p, fuse_alpha=args.fuse_alpha, fuse_beta=args.fuse_beta)
             launches, vphase, collectives, fuse_p = cg_tmp.launches_per_body(), cg_tmp.vector_phase(), cg_tmp.collectives_per_body(), cg_tmp.fuse_p()
             cg_tmp.free()
         rccl = (ctypes.c_int * 3)()
@@ -961,7 +961,7 @@ def run_rank(args):
                 for fmt, sigma in specs:
                     with quiet_stdout():
                         pr = hostapi.Problem("irregular", 24, 24, 24, fmt=fmt, Cc=64, sigma=sigma)
-                    cgp = hostapi.CG(pr, fused=args.fused, fuse_p=args.fuse_p, fuse_alpha=args.fuse_alpha)
+                    cgp = hostapi.CG(pr, fused=args.fused, fuse_p=args.fuse_p, fuse_alpha=args.fuse_alpha, fuse_beta=args.fuse_beta)
                     kk = cgp.solve(gold["itermax"], 0.0)
                     rr, pap = cgp.history()
                     cgp.free()
@@ -1046,6 +1046,8 @@ def main():
                                                            "-1 (default): the library's choice")
     ap.add_argument("--fuse-alpha", type=int, default=-1, help="the alpha step inside the r update's launch (one rank): 1 / 0, -1 (default): "
                                                                "the library's choice")
+    ap.add_argument("--fuse-beta", type=int, default=-1, help="the beta step at the head of the p update where that is a launch of its own: "
+                                                              "1 / 0, -1 (default): the library's choice")
     ap.add_argument("--pack-mode", type=int, default=-1,
                     help="SpMV stream: 0 reference layout, 5 masked row programs + LDS x-window where the matrix qualifies "
                          "(default -1: the library's choice); 1-3 intermediate forms (lab builds only)")

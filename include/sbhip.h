@@ -272,6 +272,12 @@ int sb_cg_fuse_p(sb_cg* s);
  * values itself in the canonical order (identical bits everywhere), workgroup 0 records the step -- one launch fewer per loop
  * body on one rank (sb_cg_launches_per_body tells).  on = 1 / 0, -1 = default (SB_FUSE_ALPHA, else on).  Same bits. */
 void sb_cg_set_fuse_alpha(sb_cg* s, int on);
+/* The beta step / loop test (src/CGSolver.c:107, :111-113, :116) at the head of the next body's p update, where that is a launch
+ * of its own (not inside the SpMV): taken by every workgroup, recorded by workgroup 0.  One rank: each workgroup reduces the r.r
+ * values itself; several ranks on the communicator's collectives: the all-reduced sum is read, the third launch of the dot goes
+ * (as for alpha: sb_cg_set_fuse_alpha).  Every sb_cg_run_iters call still leaves the loop state complete (a step left owing at
+ * its end is taken by a launch of its own).  on = 1 / 0, -1 = default (SB_FUSE_BETA, else on).  Same bits. */
+void sb_cg_set_fuse_beta(sb_cg* s, int on);
 void sb_cg_set_graph(sb_cg* s, int use_graph);
 /* Runs solveCG's whole loop without host synchronisation; returns k exactly as
  * the reference does (src/CGSolver.c:140).  Blocking. */

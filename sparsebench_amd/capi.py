@@ -32,7 +32,7 @@ SYMBOLS = [
     "sb_comm_init_transport", "sb_comm_p2p_reason", "sb_halo_p2p_reason",
     "sb_comm_data_plane", "sb_comm_data_plane_selected", "sb_comm_rccl_info", "sb_cg_phase_timing", "sb_cg_phase_ms",
     "sb_comm_halo_push_inside", "sb_lab_build", "sb_cg_collectives_per_body",
-    "sb_cg_set_fuse_p", "sb_cg_fuse_p", "sb_cg_set_fuse_alpha",
+    "sb_cg_set_fuse_p", "sb_cg_fuse_p", "sb_cg_set_fuse_alpha", "sb_cg_set_fuse_beta",
 ]
 
 _lib = None
@@ -145,6 +145,7 @@ def load():
         "sb_cg_set_fuse_p": (None, [vp, C.c_int]),
         "sb_cg_fuse_p": (C.c_int, [vp]),
         "sb_cg_set_fuse_alpha": (None, [vp, C.c_int]),
+        "sb_cg_set_fuse_beta": (None, [vp, C.c_int]),
         "sb_comm_rccl_info": (C.c_int, [C.POINTER(C.c_int)]),
         "sb_cg_phase_timing": (None, [vp, C.c_int]),
         "sb_cg_phase_ms": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -39,6 +39,11 @@ struct CgScalars {
   int hist_cap;
   int x_pending;  // 1: x += alpha p of the last body is still owed (applied by the next p update)
   int p2p_error;  // 1: a peer's contribution to an in-kernel all-reduce did not arrive in time
+  // what the NEXT beta step will read of this block, copied by every alpha step (cg_apply<2>): where the beta step rides at
+  // the head of the p update (cg_update_p<BETA>) every workgroup takes it from these fields while workgroup 0 is already
+  // overwriting rr / iters / stop_next with the step's results -- a late workgroup must not see the new values
+  double snap_rr;
+  int snap_iters, snap_stop_next;
 };
 
 // ---- wave-level fixed-order reductions --------------------------------------
@@ -187,6 +192,7 @@ __device__ __forceinline__ void cg_apply(CgScalars* S, const CgScalars& in, doub
     if (defer_x) S->x_pending = 1; // the body that just ran left "x += alpha p" to the next p update
   } else {
     S->x_pending    = 0; // consumed by the p update that preceded this SpMV
+    S->snap_rr = in.rr, S->snap_iters = in.iters, S->snap_stop_next = in.stop_next;
     S->pAp          = total;
     const double al = in.rr / total;
     S->alpha        = al;
@@ -516,8 +522,15 @@ __global__ __launch_bounds__(256) void waxpby_sdev_k(uint32_t n, const double* x
 // If x != NULL and the previous body left its "x = x + alpha p" (:127) pending, it is
 // applied here, where the old p is in registers anyway (saves one read of p per
 // iteration); the arithmetic and its order per element are unchanged.
+//
+// BETA != 0 (which = 0 only; 1024-thread workgroups): the beta step / loop test the previous body left owing (:107, :111-113,
+// :116) rides at the head of this launch, taken by EVERY workgroup -- nobody waits for anybody; workgroup 0 also records it
+// in the control block (cg_apply<1>).  BETA = 1 (one rank): each workgroup reduces the m level-1 values of r.r itself in
+// the canonical order; BETA = 2 (several ranks on the communicator's collectives): r.r is already reduced and all-reduced
+// into S->local by the two launches before.  One launch per dot fewer either way; same operations, same order, same bits.
+template <int BETA>
 __global__ __launch_bounds__(1024) void cg_update_p(uint32_t n, const double* __restrict__ r,
-    double* p, double* x, const CgScalars* __restrict__ S, int which)
+    double* p, double* x, CgScalars* S, int which, uint32_t m, const double* __restrict__ rrL1, double* __restrict__ rr_hist)
 {
   const uint32_t n2     = n >> 1;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -537,11 +550,30 @@ __global__ __launch_bounds__(1024) void cg_update_p(uint32_t n, const double* __
     if (useX) xv = x2[j];
   };
   if (n2) load(min(i, last), a0, b0, x0), load(min(i + stride, last), a1, b1, x1);
-  const int stopped  = S->stop;
-  const double beta  = which == 0 ? S->beta : 0.0;
-  const bool owed    = useX && S->x_pending;
-  const double alpha = S->alpha;
-  if (stopped) return;
+  double beta, alpha;
+  bool owed;
+  if (BETA) {
+    __shared__ double lds16[16];
+    const bool recorder = blockIdx.x == 0 && threadIdx.x == 0;
+    CgScalars in;
+    if (recorder) in = *S; // (only the recorder needs all of it)
+    // (stop: a late workgroup may already see the flag the recorder raises when the loop test fails -- the same outcome)
+    const int stopped = S->stop, iters = S->snap_iters, itermax = S->itermax, stop_next = S->snap_stop_next;
+    const double rr = S->snap_rr, total2 = S->local;
+    alpha = S->alpha;
+    const double total = BETA == 1 ? reduce_final_1024(m, rrL1, lds16, 1) : total2;
+    if (stopped) return;
+    if (recorder && !in.stop) cg_apply<1>(S, in, total, rr_hist, (double*)nullptr, 1);
+    if (!(iters + 1 < itermax && !stop_next)) return; // the loop test failed (cg_apply<1> has raised the stop flag): p stays
+    beta = total / rr; // (= cg_apply<1>'s S->beta)
+    owed = useX;       // (the body that left the step owing also left its x update: defer_x)
+  } else {
+    const int stopped = S->stop;
+    beta  = which == 0 ? S->beta : 0.0;
+    owed  = useX && S->x_pending;
+    alpha = S->alpha;
+    if (stopped) return;
+  }
   auto finish = [&](uint32_t j, const double2& a, const double2& b, double2 xv) {
     if (owed) {
       xv.x = xv.x + alpha * b.x;
@@ -661,7 +693,9 @@ __global__ __launch_bounds__(256) void dot_spans_k(uint32_t n, const double* a, 
 // waits for anybody -- unlike the lead kernels of `fused = 3`, where workgroup 0 published and the others polled --, the
 // price is m * 8 bytes of L2 reads per workgroup (64 KB at 128^3, 512 workgroups) behind the first group's r / Ap loads,
 // which are already in flight.  One launch and its boundary fewer per loop body; same operations, same order, same bits.
-template <bool ALPHA>
+// ALPHA = 2 (several ranks on the communicator's collectives): p.Ap is already reduced and all-reduced into S->local by the
+// two launches before; every workgroup divides, workgroup 0 records -- the third launch of that dot goes.
+template <int ALPHA>
 __global__ __launch_bounds__(1024) void cg_update_r_k(uint32_t n, const double* __restrict__ Ap, double* r,
     CgScalars* S, double* __restrict__ l1out, const int* stop, uint32_t m, const double* __restrict__ pApL1,
     double* __restrict__ rr_hist, double* __restrict__ pAp_hist)
@@ -686,7 +720,8 @@ __global__ __launch_bounds__(1024) void cg_update_r_k(uint32_t n, const double* 
     if (recorder) in = *S; // (prefetched next to the partials; only the recorder needs all of it)
     const int stopped  = S->stop;
     const double rr    = S->rr;
-    const double total = reduce_final_1024(m, pApL1, lds16, 1);
+    const double total2 = S->local;
+    const double total  = ALPHA == 1 ? reduce_final_1024(m, pApL1, lds16, 1) : total2;
     if (stopped) return;
     nalpha = -(rr / total); // (= cg_apply<2>'s neg_alpha: -(in.rr / total))
     if (recorder) cg_apply<2>(S, in, total, rr_hist, pAp_hist, 0);

@@ -282,6 +282,8 @@ struct sb_cg {
   int fusepPlan = -1; // 1: the loop uses spmv_prog_fusep, 0: not, -1: not decided yet
   int fusepWant = -1; // sb_cg_set_fuse_p: 1 / 0, -1: SB_FUSE_P or the library default
   int fuseAlphaWant = -1; // sb_cg_set_fuse_alpha: 1 / 0, -1: SB_FUSE_ALPHA or the library default (on)
+  int fuseBetaWant  = -1; // sb_cg_set_fuse_beta
+  int betaFold      = 0;  // 1 / 2: the last enqueued body left its beta step to the next p update (fold mode)
   CgScalars* S;
   double* partials;
   uint32_t nPartials;

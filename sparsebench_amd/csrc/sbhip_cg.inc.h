@@ -172,7 +172,8 @@ int sb_cg_vector_phase(sb_cg* s) { return vphase_plan(s) ? s->vSP : 0; }
 
 template <int MODE> static void scalar_launch(sb_cg* s, int defer_x, const double* q, int l1 = 0);
 static int pAp_is_level1(const sb_cg* s);
-static bool fusealpha_plan(sb_cg* s, int l1, uint32_t vb);
+static int fusealpha_plan(sb_cg* s, int l1, uint32_t vb);
+static int fusebeta_plan(sb_cg* s, uint32_t vb);
 
 #ifdef SB_LAB
 
@@ -214,6 +215,7 @@ int sb_cg_launches_per_body(sb_cg* s)
 {
   int base = vphase_plan(s) ? 2 : lead_plan(s) ? 3 : fusep_plan(s) ? 4 : s->fused ? 5 : 0;
   if (base >= 4 && fusealpha_plan(s, fusep_plan(s) ? 1 : pAp_is_level1(s), 1024u)) base -= 1; // (alpha step inside the r update)
+  if (base >= 4 && fusebeta_plan(s, 1024u)) base -= 1;                                          // (beta step inside the p update)
   if (!multi_rank() || base == 0) return base;
   int n = base;
   if (s->halo) {
@@ -397,32 +399,68 @@ template <int MODE> static void scalar_launch(sb_cg* s, int defer_x, const doubl
 // 1: the SpMV's fused dot wrote LEVEL-1 values of p.Ap (one per 256 rows), 0: level-0 partials (dot pass, lab kernels)
 static int pAp_is_level1(const sb_cg* s) { return spmv_can_fuse_dot(s) && spmv_dot_kind(s->A) == 2 ? 1 : 0; }
 
-// The alpha step inside the r update's launch (cg_update_r_k<true>: every workgroup reduces the p.Ap values itself):
-// one rank (on several the step carries the all-reduce), level-1 values from the producer, 1024-thread workgroups.
-// SB_FUSE_ALPHA=0 / sb_cg_set_fuse_alpha(s, 0): the separate scalar launch.
-static bool fusealpha_plan(sb_cg* s, int l1, uint32_t vb)
+// The scalar steps inside their consumers' launches (kernels.hip.h: cg_update_r_k<ALPHA>, cg_update_p<BETA>): EVERY workgroup of
+// the consumer takes the step itself -- nobody waits for anybody --, workgroup 0 records it.  Returns the mode: 0 the separate
+// scalar launch; 1 (one rank) each workgroup reduces the producer's level-1 values itself; 2 (several ranks on the
+// communicator's collectives) the sum is already reduced and all-reduced into S->local by the two launches before, the third
+// launch of that dot goes.  The peer-mapped plane keeps its one-launch step (local reduce, exchange and step: cg_scalar_p2p_k).
+// Needs level-1 values from the producer and 1024-thread workgroups.  SB_FUSE_ALPHA=0 / sb_cg_set_fuse_alpha(s, 0) and
+// SB_FUSE_BETA=0 / sb_cg_set_fuse_beta(s, 0): the separate launches.
+static int fold_mode(sb_cg* s, int l1, uint32_t vb)
 {
-  if (multi_rank() || !s->fused || !l1 || vb != 1024u || vphase_plan(s) || lead_plan(s)) return false;
+  if (!s->fused || !l1 || vb != 1024u || vphase_plan(s) || lead_plan(s)) return 0;
+  if (multi_rank()) return p2p_dots() ? 0 : 2;
+  return 1;
+}
+static int fusealpha_plan(sb_cg* s, int l1, uint32_t vb)
+{
   static const int env = getenv("SB_FUSE_ALPHA") ? atoi(getenv("SB_FUSE_ALPHA")) != 0 : -1;
-  return s->fuseAlphaWant >= 0 ? s->fuseAlphaWant != 0 : env >= 0 ? env != 0 : true;
+  const bool want = s->fuseAlphaWant >= 0 ? s->fuseAlphaWant != 0 : env >= 0 ? env != 0 : true;
+  return want ? fold_mode(s, l1, vb) : 0;
+}
+// (the beta step rides in the p update's launch: only where the p update is a launch of its own, i.e. not inside the SpMV)
+static int fusebeta_plan(sb_cg* s, uint32_t vb)
+{
+  static const int env = getenv("SB_FUSE_BETA") ? atoi(getenv("SB_FUSE_BETA")) != 0 : -1;
+  const bool want = s->fuseBetaWant >= 0 ? s->fuseBetaWant != 0 : env >= 0 ? env != 0 : true;
+  if (!want || fusep_plan(s) || s->use_graph) return 0;
+  return fold_mode(s, 1, vb);
 }
 void sb_cg_set_fuse_alpha(sb_cg* s, int on) { s->fuseAlphaWant = on < 0 ? -1 : on != 0; }
+void sb_cg_set_fuse_beta(sb_cg* s, int on) { s->fuseBetaWant = on < 0 ? -1 : on != 0; }
+
+// several ranks, communicator's collectives: local levels 1-2 of a dot into S->local, all-reduced in place on the stream
+// (MPI_Allreduce of src/comm.c:659); the step itself is taken by the consumer (fold mode 2) or by cg_scalar_k<MODE, false>
+template <int MODE> static void scalar_reduce_only(sb_cg* s, const double* q, int l1)
+{
+  hipLaunchKernelGGL((cg_scalar_k<MODE, true>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, q, s->S, s->rr_hist, s->pAp_hist, 1, 0, l1);
+  HIP_CHECK(hipGetLastError());
+  mark(s, R_DDOT);
+  sb_comm_reduction(&s->S->local, 1);
+  mark(s, R_COMM);
+}
 
 // alpha step (src/CGSolver.c:124-126) and r -= alpha Ap + the r.r values of the next body (:128, :112): two launches, or one
 static void alpha_and_r_update(sb_cg* s, int l1, uint32_t capV, uint32_t vb, const int* stop)
 {
   const uint32_t n = s->nr;
   const dim3 grid(std::max(1u, std::min(capV, (((n + 255u) >> 8) + vb / 64 - 1) / (vb / 64))));
-  if (fusealpha_plan(s, l1, vb)) {
+  const int mode = fusealpha_plan(s, l1, vb);
+  if (mode) {
     // one workgroup per CU (the separate r update runs two): every workgroup reads all m values, so half the workgroups is half
     // that traffic -- 128^3, same box, alternating: 41.6 / 42.1 us per iteration against 42.4 / 42.7 with two (and 43.8 / 44.2
     // with the separate alpha launch)
     static const uint32_t perCu = getenv("SB_ALPHA_WG_PER_CU") ? (uint32_t)std::max(1, atoi(getenv("SB_ALPHA_WG_PER_CU"))) : 1u;
     const dim3 gridA(std::max(1u, std::min((uint32_t)g.prop.multiProcessorCount * perCu, grid.x)));
-    hipLaunchKernelGGL(cg_update_r_k<true>, gridA, dim3(vb), 0, g.stream, n, s->Ap, s->r, s->S, s->partials2, stop, s->nPartials,
-        (const double*)s->partials, s->rr_hist, s->pAp_hist);
+    if (mode == 2) {
+      scalar_reduce_only<2>(s, s->partials, l1);
+      phase_mark(s, PH_ALPHA);
+      hipLaunchKernelGGL(cg_update_r_k<2>, grid, dim3(vb), 0, g.stream, n, s->Ap, s->r, s->S, s->partials2, stop, s->nPartials,
+          (const double*)s->partials, s->rr_hist, s->pAp_hist);
+    } else
+      hipLaunchKernelGGL(cg_update_r_k<1>, gridA, dim3(vb), 0, g.stream, n, s->Ap, s->r, s->S, s->partials2, stop, s->nPartials,
+          (const double*)s->partials, s->rr_hist, s->pAp_hist);
     HIP_CHECK(hipGetLastError());
-    mark(s, R_DDOT);
     mark(s, R_WAXPBY);
     phase_mark(s, PH_R_UPDATE);
     return;
@@ -430,11 +468,38 @@ static void alpha_and_r_update(sb_cg* s, int l1, uint32_t capV, uint32_t vb, con
   scalar_launch<2>(s, 0, nullptr, l1);
   mark(s, R_DDOT);
   phase_mark(s, PH_ALPHA);
-  hipLaunchKernelGGL(cg_update_r_k<false>, grid, dim3(vb), 0, g.stream, n, s->Ap, s->r, s->S, s->partials2, stop, 0u,
+  hipLaunchKernelGGL(cg_update_r_k<0>, grid, dim3(vb), 0, g.stream, n, s->Ap, s->r, s->S, s->partials2, stop, 0u,
       (const double*)nullptr, (double*)nullptr, (double*)nullptr);
   HIP_CHECK(hipGetLastError());
   mark(s, R_WAXPBY);
   phase_mark(s, PH_R_UPDATE);
+}
+
+// beta step / loop test behind the r update (:107, :111-113, :116): its own launch(es), or left owing to the next body's p
+// update (cg_update_p<BETA>; flush_beta_fold takes it where no body follows)
+static void beta_step_or_owe(sb_cg* s, uint32_t vb)
+{
+  const int mode = fusebeta_plan(s, vb);
+  if (mode) {
+    if (mode == 2) scalar_reduce_only<1>(s, s->partials2, 1);
+    s->betaFold = mode;
+    return;
+  }
+  scalar_launch<1>(s, 1, s->partials2, 1);
+  mark(s, R_DDOT);
+  phase_mark(s, PH_BETA);
+}
+static void flush_beta_fold(sb_cg* s)
+{
+  if (!s->betaFold) return;
+  if (s->betaFold == 2) { // r.r is in S->local already
+    hipLaunchKernelGGL((cg_scalar_k<1, false>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, (const double*)s->partials2, s->S,
+        s->rr_hist, s->pAp_hist, 0, 1, 0);
+    HIP_CHECK(hipGetLastError());
+  } else scalar_launch<1>(s, 1, s->partials2, 1);
+  mark(s, R_DDOT);
+  phase_mark(s, PH_BETA);
+  s->betaFold = 0;
 }
 
 static void spmv_event(sb_cg* s)
@@ -545,7 +610,7 @@ static void loop_body(sb_cg* s, int k)
     return;
   }
   if (k == 1) {
-    if (n) hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, (double*)nullptr, s->S, 1); // p = r (:109)
+    if (n) hipLaunchKernelGGL(cg_update_p<0>, gridV, blockV, 0, g.stream, n, s->r, s->p, (double*)nullptr, s->S, 1, 0u, (const double*)nullptr, (double*)nullptr); // p = r (:109)
     mark(s, R_WAXPBY);
     phase_mark(s, PH_P_UPDATE);
   } else if (vphase_plan(s)) {
@@ -561,8 +626,16 @@ static void loop_body(sb_cg* s, int k)
       mark(s, R_DDOT);
       phase_mark(s, PH_BETA);
     }
-    if (n) // p = r + beta p (:114); fused path: also the x update owed by the previous body (:127)
-      hipLaunchKernelGGL(cg_update_p, gridV, blockV, 0, g.stream, n, s->r, s->p, s->fused ? s->x : (double*)nullptr, s->S, 0);
+    // p = r + beta p (:114); fused path: also the x update owed by the previous body (:127) -- and, where the previous body left
+    // its beta step / loop test owing, that step at the head of this launch
+    if (s->betaFold == 2)
+      hipLaunchKernelGGL(cg_update_p<2>, gridV, blockV, 0, g.stream, n, s->r, s->p, s->x, s->S, 0, s->nPartials, (const double*)s->partials2, s->rr_hist);
+    else if (s->betaFold == 1)
+      hipLaunchKernelGGL(cg_update_p<1>, gridV, blockV, 0, g.stream, n, s->r, s->p, s->x, s->S, 0, s->nPartials, (const double*)s->partials2, s->rr_hist);
+    else if (n)
+      hipLaunchKernelGGL(cg_update_p<0>, gridV, blockV, 0, g.stream, n, s->r, s->p, s->fused ? s->x : (double*)nullptr, s->S, 0, 0u,
+          (const double*)nullptr, (double*)nullptr);
+    s->betaFold = 0;
     mark(s, R_WAXPBY);
     phase_mark(s, PH_P_UPDATE);
   }
@@ -641,9 +714,7 @@ static void loop_body(sb_cg* s, int k)
   if (s->fused) { // alpha; r -= alpha Ap (:128) + next r.r, beta, loop test; x += alpha p (:127) is owed
     // (level-1 values of r.r into partials2: `partials` keeps the layout the p.Ap producers write)
     alpha_and_r_update(s, pAp_is_level1(s), capV, vb, stop);
-    scalar_launch<1>(s, 1, s->partials2, 1);
-    mark(s, R_DDOT);
-    phase_mark(s, PH_BETA);
+    beta_step_or_owe(s, vb);
     return;
   }
   scalar_launch<2>(s, 0, nullptr, pAp_is_level1(s));
@@ -726,6 +797,7 @@ void sb_cg_start(sb_cg* s, int itermax, double eps)
   s->k_next   = 1;
   s->started  = true;
   s->betaOwed = false;
+  s->betaFold = 0;
 }
 
 void sb_cg_run_iters(sb_cg* s, int iters)
@@ -735,6 +807,7 @@ void sb_cg_run_iters(sb_cg* s, int iters)
   phase_mark(s, -1);
   for (int i = 0; i < iters; i++) run_body_maybe_graph(s, s->k_next++);
   flush_beta(s); // every call leaves the loop state complete (counters, history, stop flag)
+  flush_beta_fold(s);
 }
 
 int sb_cg_finish(sb_cg* s)

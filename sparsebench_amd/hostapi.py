@@ -187,7 +187,7 @@ class Problem:
 class CG:
     """solveCG on the GPU (sb_cg_*): state in HBM, loop without host round trips."""
 
-    def __init__(self, problem, fused=True, graph=False, fuse_p=-1, fuse_alpha=-1):
+    def __init__(self, problem, fused=True, graph=False, fuse_p=-1, fuse_alpha=-1, fuse_beta=-1):
         self.L = capi.load()
         self.problem = problem
         b, xe = problem.rhs()
@@ -199,6 +199,7 @@ class CG:
         self.L.sb_cg_set_graph(self.ptr, int(graph))
         self.L.sb_cg_set_fuse_p(self.ptr, int(fuse_p))  # -1: default; 1 / 0: the p update inside the SpMV where possible / not
         self.L.sb_cg_set_fuse_alpha(self.ptr, int(fuse_alpha))  # -1: default; 1 / 0: the alpha step inside the r update (one rank) / not
+        self.L.sb_cg_set_fuse_beta(self.ptr, int(fuse_beta))  # the beta step at the head of the p update where that is a launch of its own
         self.itermax = 0
 
     def vector_phase(self):

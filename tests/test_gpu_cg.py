@@ -26,14 +26,14 @@ def f(a):
     return np.array([float(v) for v in a])
 
 
-def run_gpu(filename, n, fmt, Cc, sigma, itermax, eps=0.0, fused=True, graph=False, pack_mode=None, pack_try=None, fuse_p=-1, fuse_alpha=-1):
+def run_gpu(filename, n, fmt, Cc, sigma, itermax, eps=0.0, fused=True, graph=False, pack_mode=None, pack_try=None, fuse_p=-1, fuse_alpha=-1, fuse_beta=-1):
     nx, ny, nz = n if isinstance(n, tuple) else (n, n, n)
     p = hostapi.Problem(filename, nx, ny, nz, fmt=fmt, Cc=Cc, sigma=sigma)
     if pack_mode is not None:
         assert p.use_packed(pack_mode) == pack_mode
     if pack_try is not None:
         p.use_packed(pack_try)  # clamped to what the matrix has (CRS: its pattern mirror, if any)
-    cg = hostapi.CG(p, fused=fused, graph=graph, fuse_p=fuse_p, fuse_alpha=fuse_alpha)
+    cg = hostapi.CG(p, fused=fused, graph=graph, fuse_p=fuse_p, fuse_alpha=fuse_alpha, fuse_beta=fuse_beta)
     k = cg.solve(itermax, eps)
     rr, pap = cg.history()
     out = dict(k=k, rr=rr, pAp=pap, x=cg.solution(), err=cg.check_residual(), fuse_p=cg.fuse_p(), launches=cg.launches_per_body())
@@ -74,7 +74,7 @@ def test_p_update_inside_the_spmv_same_bits(gpu, dims, fmt, sigma):
     g = po.GMatrix.generate(*dims)
     o = po.cg(g, itermax=50, fmt=fmt, Cc=64, sigma=sigma, dot="tree", want_x=True)
     on = run_gpu("generate", dims, fmt, 64, sigma, 50, fuse_p=1)
-    off = run_gpu("generate", dims, fmt, 64, sigma, 50, fuse_p=0, fuse_alpha=0)
+    off = run_gpu("generate", dims, fmt, 64, sigma, 50, fuse_p=0, fuse_alpha=0, fuse_beta=0)
     assert off["fuse_p"] == 0 and off["launches"] == 5
     for r in (on, off):
         assert r["k"] == o["k"] and np.array_equal(r["rr"], o["rr"]) and np.array_equal(r["pAp"], o["pAp"])
@@ -108,23 +108,27 @@ def test_p_update_inside_the_spmv_same_bits(gpu, dims, fmt, sigma):
 @pytest.mark.parametrize("dims,fmt,sigma,mode", [((8, 8, 8), "scs", 1, None), ((16, 12, 10), "crs", 1, None), ((33, 7, 5), "scs", 256, None),
                                                  ((32, 32, 32), "scs", 256, 0), ((128, 8, 4), "scs", 256, None), ((128, 8, 4), "scs", 1, 0),
                                                  ((48, 48, 48), "scs", 256, None)])
-def test_alpha_step_inside_the_r_update_same_bits(gpu, dims, fmt, sigma, mode):
-    """round 3: on one rank the alpha step rides in the r update's launch (cg_update_r_k<true>: EVERY workgroup reduces the level-1
-    values of p.Ap itself, in the canonical order, workgroup 0 records the step) -- one launch fewer per loop body.  Same bits as
-    the separate scalar launch (sb_cg_set_fuse_alpha(s, 0)) and as the oracle: history, k, x, residual check, an exit through
-    eps, pieces, itermax 0..3; with the reference-layout kernel (mode 0) and the row programs, n not a multiple of 256."""
+def test_scalar_steps_inside_their_consumers_same_bits(gpu, dims, fmt, sigma, mode):
+    """round 3: on one rank the alpha step rides in the r update's launch and -- where the p update is a launch of its own -- the
+    beta step / loop test at the head of the next body's p update (cg_update_r_k<1>, cg_update_p<1>: EVERY workgroup reduces the
+    level-1 values itself, in the canonical order, workgroup 0 records the step): up to two launches fewer per loop body.  Same
+    bits as the separate scalar launches (sb_cg_set_fuse_alpha / _beta(s, 0)) and as the oracle: history, k, x, residual check,
+    an exit through eps, pieces (a step left owing at the end of a piece is taken by a launch of its own), itermax 0..3; with the
+    reference-layout kernel (mode 0) and the row programs, n not a multiple of 256."""
     g = po.GMatrix.generate(*dims)
     o = po.cg(g, itermax=40, fmt=fmt, Cc=64, sigma=sigma, dot="tree", want_x=True)
-    on = run_gpu("generate", dims, fmt, 64, sigma, 40, pack_try=mode, fuse_alpha=1)
-    off = run_gpu("generate", dims, fmt, 64, sigma, 40, pack_try=mode, fuse_alpha=0)
-    assert on["launches"] == off["launches"] - 1 or (fmt == "crs" and mode is None and on["launches"] in (off["launches"], off["launches"] - 1))
-    for r in (on, off):
+    runs = {(a, b): run_gpu("generate", dims, fmt, 64, sigma, 40, pack_try=mode, fuse_alpha=a, fuse_beta=b) for a in (1, 0) for b in (1, 0)}
+    for r in runs.values():
         assert r["k"] == o["k"] and np.array_equal(r["rr"], o["rr"]) and np.array_equal(r["pAp"], o["pAp"])
         assert np.array_equal(r["x"], o["x"][0]) and r["err"] == o["max_err"]
+    base = runs[(0, 0)]["launches"]
+    if not (fmt == "crs" and mode is None):  # (a CRS matrix without a mirror: level-0 partials from the dot pass, nothing folds)
+        assert runs[(1, 0)]["launches"] == base - 1
+        assert runs[(1, 1)]["launches"] == base - (1 if runs[(1, 1)]["fuse_p"] else 2)  # (p update inside the SpMV: the beta step stays)
     p = hostapi.Problem("generate", *dims, fmt=fmt, Cc=64, sigma=sigma)
     if mode is not None:
         p.use_packed(mode)
-    cg = hostapi.CG(p, fuse_alpha=1)
+    cg = hostapi.CG(p, fuse_alpha=1, fuse_beta=1)
     oe = po.cg(g, itermax=40, eps=1e-2, fmt=fmt, Cc=64, sigma=sigma, dot="tree", want_x=True)
     assert cg.solve(40, 1e-2) == oe["k"]
     rr, pap = cg.history()
@@ -153,7 +157,7 @@ def test_launches_per_body_variants(gpu):
     # (the product: 1 and 0; a request for the lab-only levels 2 / 3 behaves as 1 there)
     for fused, want in (((1, 5), (3, 3), (2, 2), (0, 0)) if lab_build() else ((1, 5), (0, 0), (3, 5), (2, 5))):
         p = hostapi.Problem("generate", 24, 20, 16, fmt="scs", Cc=64, sigma=1)
-        cg = hostapi.CG(p, fused=fused, fuse_p=0, fuse_alpha=0)  # (the p update inside the SpMV, the alpha step inside the r update: tests of their own)
+        cg = hostapi.CG(p, fused=fused, fuse_p=0, fuse_alpha=0, fuse_beta=0)  # (the p update inside the SpMV, the scalar steps inside their consumers: tests of their own)
         assert cg.launches_per_body() == want
         assert cg.solve(70, 0.0) == o["k"]
         rr, pap = cg.history()
