@@ -810,6 +810,31 @@ struct P2PView {
 // is generous (default 30 s inside CG, SB_P2P_TIMEOUT_MS) because a merely LATE peer (first-kernel load, OS
 // jitter) must not be fatal -- RCCL would simply wait.  The set-up self-tests use 5 s.
 constexpr long long P2P_TICKS_PER_MS = 100000ll;
+// A rank whose bounded wait ran out (or that was told so by a peer) leaves the loop -- and must not leave the others sitting
+// out their own 30 s: from then on it writes P2P_POISON where it would have published a sequence number (all-reduce slots,
+// halo flags), and every wait treats that value as "the peer has failed": the whole job ends within microseconds of the
+// first failure, and only the rank that saw the cause reports it as one (CgScalars::p2p_error for the all-reduce, the halo
+// plan's err for the halo waits: 1 = the wait ran out HERE, 2 = another rank reported a failure).
+constexpr unsigned long long P2P_POISON = ~0ull;
+// bounded wait for *f == seq: 0 it arrived, 1 timed out, 2 the peer has failed
+__device__ __forceinline__ int p2p_wait(const unsigned long long* f, unsigned long long seq, long long timeoutTicks)
+{
+  const long long t0 = wall_clock64();
+  for (;;) {
+    const unsigned long long got = __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (got == seq) return 0;
+    if (got == P2P_POISON) return 2;
+    if (wall_clock64() - t0 > timeoutTicks) return 1;
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+// a halo wait failed (how: p2p_wait's 1 / 2): raise the halo plan's error flag (the cause; the rank's next push / scalar
+// kernels see it and poison what they would have published) and the stop flag
+__device__ __forceinline__ void halo_wait_failed(int how, int* err, int* stopw)
+{
+  atomicExch(err, how);
+  if (stopw) atomicExch(stopw, 1); // the loop must not go on iterating on a stale halo
+}
 
 // every thread of the workgroup calls this with the same `mine`; returns the same sum in every thread
 __device__ __forceinline__ double p2p_allreduce_sum(const P2PView* pv, double mine, unsigned long long seq,
@@ -823,19 +848,11 @@ __device__ __forceinline__ double p2p_allreduce_sum(const P2PView* pv, double mi
         __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     P2PSlot* src       = pv->peer[pv->rank] + par * P2P_MAX + t;
-    const long long t0 = wall_clock64();
-    bool ok            = true;
-    while (__hip_atomic_load(&src->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-      if (wall_clock64() - t0 > pv->timeoutTicks) {
-        ok = false;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(4);
-    }
-    sh[t] = ok ? __longlong_as_double((long long)__hip_atomic_load(&src->bits, __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_SYSTEM))
-               : 0.0;
-    if (!ok) atomicExch(err, 1);
+    const int how = p2p_wait(&src->seq, seq, pv->timeoutTicks);
+    sh[t] = !how ? __longlong_as_double((long long)__hip_atomic_load(&src->bits, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM))
+                 : 0.0;
+    if (how) atomicCAS(err, 0, how); // 1: timed out, 2: the peer has failed (the first cause stays)
   }
   __syncthreads();
   // pairwise tree in rank order: ((v0+v1)+(v2+v3))+... (an odd tail moves up unchanged)
@@ -885,11 +902,26 @@ struct HaloPush {
   unsigned long long* flag[P2P_MAX];  // destination i's flags
   uint32_t ext[P2P_MAX];              // destination i's externalCount (area stride)
   long long timeoutTicks;             // bound of the receivers' waits (halo_pull_k, HALO SpMV)
+  unsigned long long dropSeq;         // test hook (SB_TEST_DROP_PUSH_RANK / _AT): the exchange this rank does not announce
+  const int* err;                     // the halo plan's error flag (a failed wait of THIS rank) ...
+  const int* p2pErr;                  // ... and the control block's (a failed all-reduce; NULL outside CG): push kernels poison on either
 };
+__device__ __forceinline__ bool halo_rank_failed(const HaloPush& hp)
+{
+  return (hp.err && *hp.err) || (hp.p2pErr && *hp.p2pErr);
+}
 
 // the push of one workgroup out of nBlocks (its own kernel below; or the first workgroups of the HALO SpMV)
 // FUSEP: the values to send are not in memory yet -- the SpMV that follows forms p_new = r + beta p_old while it stages its
 // windows (pack.hip.h: spmv_prog_fusep) -- so the push forms them itself, with the same expression: x = p_old here.
+// this rank has failed: every peer that waits for its all-reduce contribution (either parity) leaves at once
+__device__ __forceinline__ void p2p_poison_allreduce(const P2PView* pv)
+{
+  const int t = (int)threadIdx.x;
+  if (t < pv->size)
+    for (int par = 0; par < 2; par++)
+      __hip_atomic_store(&(pv->peer[t] + par * P2P_MAX + pv->rank)->seq, P2P_POISON, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 template <bool FUSEP = false>
 __device__ __forceinline__ void halo_push_block(const HaloPush& hp, const double* __restrict__ x, unsigned long long seq,
     uint32_t block, uint32_t nBlocks, const double* __restrict__ r = nullptr, double beta = 0.0)
@@ -910,23 +942,37 @@ __device__ __forceinline__ void halo_push_block(const HaloPush& hp, const double
     if (prev == nBlocks - 1u) { // every workgroup has pushed: tell the receivers
       *hp.done = 0u;
       __threadfence_system();
-      for (int d = 0; d < hp.ndest; d++)
-        __hip_atomic_store(hp.flag[d] + par * P2P_MAX + hp.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (seq != hp.dropSeq) // (test hook: this rank "forgets" to announce exchange dropSeq; 0 = never)
+        for (int d = 0; d < hp.ndest; d++)
+          __hip_atomic_store(hp.flag[d] + par * P2P_MAX + hp.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+// this rank has failed: the neighbours that wait for its halo block (either parity) leave at once.  One thread.
+__device__ __forceinline__ void halo_poison_flags(const HaloPush& hp)
+{
+  for (int d = 0; d < hp.ndest; d++)
+    for (unsigned par = 0; par < 2u; par++)
+      __hip_atomic_store(hp.flag[d] + par * P2P_MAX + hp.rank, P2P_POISON, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(256) void halo_push_k(HaloPush hp, const double* __restrict__ x,
     unsigned long long seq, const int* __restrict__ stop)
 {
-  if (stop && *stop) return; // the same decision on every rank (the loop test is all-reduced)
+  if (stop && *stop) { // the same decision on every rank (the loop test is all-reduced) -- unless this rank has failed
+    if (blockIdx.x == 0 && threadIdx.x == 0 && halo_rank_failed(hp)) halo_poison_flags(hp);
+    return;
+  }
   halo_push_block(hp, x, seq, blockIdx.x, gridDim.x);
 }
 // the push in front of spmv_prog_fusep: p_new = r + beta p_old of the boundary rows, formed here (which: k = 1, beta = 0, x = r)
 __global__ __launch_bounds__(256) void halo_push_fusep_k(HaloPush hp, const double* __restrict__ pold, const double* __restrict__ r,
     const CgScalars* __restrict__ S, int which, unsigned long long seq)
 {
-  if (S->stop) return;
+  if (S->stop) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && halo_rank_failed(hp)) halo_poison_flags(hp);
+    return;
+  }
   halo_push_block<true>(hp, pold, seq, blockIdx.x, gridDim.x, r, which ? 0.0 : S->beta);
 }
 
@@ -940,18 +986,9 @@ __global__ __launch_bounds__(256) void halo_pull_k(const int* __restrict__ srcRa
   const int j        = (int)blockIdx.x;
   if (threadIdx.x == 0) {
     const unsigned long long* f = flags + par * P2P_MAX + srcRank[j];
-    const long long t0          = wall_clock64();
-    int good                    = 1;
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-      if (wall_clock64() - t0 > timeoutTicks) {
-        good = 0;
-        atomicExch(err, 1);
-        if (stop) atomicExch(stop, 1); // the loop must not go on iterating on a stale halo
-        break;
-      }
-      __builtin_amdgcn_s_sleep(4);
-    }
-    ok = good;
+    const int how = p2p_wait(f, seq, timeoutTicks);
+    if (how) halo_wait_failed(how, err, stop);
+    ok = !how;
   }
   __syncthreads();
   if (!ok) return;
@@ -994,18 +1031,22 @@ __global__ __launch_bounds__(1024) void cg_scalar_k(uint32_t m, const double* __
 template <int MODE>
 __global__ __launch_bounds__(1024) void cg_scalar_p2p_k(uint32_t m, const double* __restrict__ q,
     CgScalars* S, double* __restrict__ rr_hist, double* __restrict__ pAp_hist, int defer_x,
-    const P2PView* __restrict__ pv, unsigned long long seq, int l1)
+    const P2PView* __restrict__ pv, unsigned long long seq, int l1, const int* __restrict__ haloErr)
 {
   __shared__ double lds16[16];
   const CgScalars in = cg_fetch(S);
-  const int stopped  = in.stop; // identical on every rank: all of them skip the exchange, or none
+  const int stopped  = in.stop; // identical on every rank: all of them skip the exchange, or none -- unless one has failed
   double total       = reduce_final_1024(m, q, lds16, l1);
-  if (stopped) return;
+  if (stopped) {
+    if (in.p2p_error || (haloErr && *haloErr)) p2p_poison_allreduce(pv); // this rank has failed: nobody waits for its contribution
+    return;
+  }
   __syncthreads(); // lds16 is reused
   total = p2p_allreduce_sum(pv, total, seq, lds16, &S->p2p_error);
   // (atomic load: the line holding p2p_error was read with the control block above, a plain load could be served stale)
   if (__hip_atomic_load(&S->p2p_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // uniform: raised before the barriers inside the exchange
     if (threadIdx.x == 0) S->stop = 1;
+    p2p_poison_allreduce(pv); // (and tell the others at once)
     return;
   }
   if (threadIdx.x == 0) cg_apply<MODE>(S, in, total, rr_hist, pAp_hist, defer_x);

@@ -717,7 +717,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(72))) /* see sp
   // that touch no halo column first, so that on several ranks the interior part of the
   // product can run while the halo is still in flight (one launch for each part).
   if (HALO && blockIdx.x < hw.nPush) { // (uniform per workgroup) this workgroup carries the rank's halo push
-    if (*stop) return;
+    if (*stop) {
+      if (blockIdx.x == 0 && threadIdx.x == 0 && halo_rank_failed(*hw.push)) halo_poison_flags(*hw.push); // this rank has failed
+      return;
+    }
     halo_push_block(*hw.push, x, hw.seq, blockIdx.x, hw.nPush);
     return;
   }
@@ -755,15 +758,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(72))) /* see sp
   if (HALO && (flags & PAT_TOUCHES_HALO) && !stopped && tile0 < nHdrs) { // wait for the neighbours' blocks
     if ((int)threadIdx.x < hw.nsrc) {
       const unsigned long long* f = hw.flags + (hw.seq & 1ull) * P2P_MAX + hw.src[threadIdx.x];
-      const long long t0          = wall_clock64();
-      while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != hw.seq) {
-        if (wall_clock64() - t0 > hw.timeoutTicks) {
-          atomicExch(hw.err, 1);
-          if (hw.stopw) atomicExch(hw.stopw, 1);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
+      const int how               = p2p_wait(f, hw.seq, hw.timeoutTicks);
+      if (how) halo_wait_failed(how, hw.err, hw.stopw);
     }
     __syncthreads();
   }
@@ -1122,7 +1118,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(72))) void spmv
   constexpr int WB   = 3 * LONG + 3;
   constexpr int H1   = 8; // slots per thread in the first half (loaded in front of the exit test)
   if (HALO && blockIdx.x < hw.nPush) { // (uniform per workgroup) this workgroup carries the rank's halo push
-    if (S->stop) return;
+    if (S->stop) {
+      if (blockIdx.x == 0 && threadIdx.x == 0 && halo_rank_failed(*hw.push)) halo_poison_flags(*hw.push); // this rank has failed
+      return;
+    }
     halo_push_block<true>(*hw.push, pold, hw.seq, blockIdx.x, hw.nPush, r, which ? 0.0 : S->beta);
     return;
   }
@@ -1151,15 +1150,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(72))) void spmv
   if (HALO && (flags & PAT_TOUCHES_HALO) && !stopped && tile0 < nHdrs) { // wait for the neighbours' blocks
     if ((int)threadIdx.x < hw.nsrc) {
       const unsigned long long* f = hw.flags + (hw.seq & 1ull) * P2P_MAX + hw.src[threadIdx.x];
-      const long long t0          = wall_clock64();
-      while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != hw.seq) {
-        if (wall_clock64() - t0 > hw.timeoutTicks) {
-          atomicExch(hw.err, 1);
-          if (hw.stopw) atomicExch(hw.stopw, 1);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
+      const int how               = p2p_wait(f, hw.seq, hw.timeoutTicks);
+      if (how) halo_wait_failed(how, hw.err, hw.stopw);
     }
     __syncthreads();
   }

@@ -64,6 +64,10 @@ sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host, con
     HIP_CHECK(hipStreamSynchronize(g.stream));
   }
   s->S         = (CgScalars*)sb_malloc(sizeof(CgScalars));
+  if (halo && halo->p2p) { // the push kernels of this loop also look at its control block's failure flag (poisoning: kernels.hip.h)
+    halo->push.p2pErr = &s->S->p2p_error;
+    HIP_CHECK(hipMemcpy(halo->dPush, &halo->push, sizeof halo->push, hipMemcpyHostToDevice));
+  }
   s->nPartials = (m->nr + 255) / 256;
   // level-0 partials: 4 per 256 rows; the tail beyond the last chunk stays +0.0
   s->partials = (double*)sb_malloc((4 * (size_t)s->nPartials + 4) * sizeof(double));
@@ -99,6 +103,10 @@ void sb_cg_free(sb_cg* s)
 {
   if (!s) return;
   HIP_CHECK(hipStreamSynchronize(g.stream));
+  if (s->halo && s->halo->p2p && s->halo->push.p2pErr == &s->S->p2p_error) {
+    s->halo->push.p2pErr = nullptr;
+    HIP_CHECK(hipMemcpy(s->halo->dPush, &s->halo->push, sizeof s->halo->push, hipMemcpyHostToDevice));
+  }
   if (s->iterGraph) HIP_CHECK(hipGraphExecDestroy(s->iterGraph));
   for (hipEvent_t e : s->ev) HIP_CHECK(hipEventDestroy(e));
   for (hipEvent_t e : s->spmvEv) HIP_CHECK(hipEventDestroy(e));
@@ -379,7 +387,8 @@ template <int MODE> static void scalar_launch(sb_cg* s, int defer_x, const doubl
   if (!q) q = s->partials;
   if (multi_rank() && p2p_dots()) { // local reduce, in-kernel all-reduce and scalar step in ONE launch
     hipLaunchKernelGGL((cg_scalar_p2p_k<MODE>), dim3(1), dim3(1024), 0, g.stream, s->nPartials, q,
-        s->S, s->rr_hist, s->pAp_hist, defer_x, (const P2PView*)g.p2pView, ++g.p2pSeq, l1);
+        s->S, s->rr_hist, s->pAp_hist, defer_x, (const P2PView*)g.p2pView, ++g.p2pSeq, l1,
+        (const int*)(s->halo && s->halo->p2p ? s->halo->err : nullptr));
     HIP_CHECK(hipGetLastError());
     return;
   }
@@ -838,17 +847,23 @@ int sb_cg_finish(sb_cg* s)
                "work (set SB_SHARED_GPU=1 or SB_VPHASE=0 to use the separate launches)", g.rank);
   }
 #endif
+  // (a rank that fails poisons what it would have published, so the others leave their waits at once with code 2: the rank
+  //  that saw the CAUSE -- code 1 or 3 -- is the one whose message matters)
+  if (s->halo && s->halo->p2p) {
+    int e = 0;
+    HIP_CHECK(hipMemcpy(&e, s->halo->err, sizeof e, hipMemcpyDeviceToHost));
+    if (e == 1)
+      SB_FATAL("rank %d: a neighbour's halo block did not arrive within %lld ms (SB_P2P_TIMEOUT_MS raises the bound, "
+               "SB_P2P_HALO=0 selects RCCL)", g.rank, s->halo->push.timeoutTicks / P2P_TICKS_PER_MS);
+    if (e && h.p2p_error != 1) h.p2p_error = 2;
+  }
+  if (h.p2p_error == 2)
+    SB_FATAL("rank %d: another rank reported a communication failure over the peer-mapped paths and ended the exchange "
+             "(its own message says which wait ran out); this rank stopped with it", g.rank);
   if (h.p2p_error)
     SB_FATAL("rank %d: a peer's contribution to an in-kernel all-reduce did not arrive within %lld ms "
              "(SB_P2P_TIMEOUT_MS raises the bound, SB_P2P=0 selects the RCCL all-reduce)", g.rank,
         g.p2pTimeoutTicks / P2P_TICKS_PER_MS);
-  if (s->halo && s->halo->p2p) {
-    int e = 0;
-    HIP_CHECK(hipMemcpy(&e, s->halo->err, sizeof e, hipMemcpyDeviceToHost));
-    if (e)
-      SB_FATAL("rank %d: a neighbour's halo block did not arrive within %lld ms (SB_P2P_TIMEOUT_MS raises the bound, "
-               "SB_P2P_HALO=0 selects RCCL)", g.rank, g.p2pTimeoutTicks / P2P_TICKS_PER_MS);
-  }
   if (s->timing) {
     for (double& v : s->region_ms) v = 0.0;
     for (size_t i = 1; i < s->evUsed; i++) {

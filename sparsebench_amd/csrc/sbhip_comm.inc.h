@@ -479,6 +479,7 @@ static void halo_p2p_setup(sb_halo* h)
     h->dRcount  = (int*)upload(h->recvCounts.data(), h->recvCounts.size() * sizeof(int));
     h->push.n = (uint32_t)h->totalSend, h->push.ndest = h->outdegree, h->push.rank = g.rank;
     h->push.packIdx = h->packIdx, h->push.slot = h->slot, h->push.dest = h->dest, h->push.done = h->done;
+    h->push.err = h->err, h->push.p2pErr = nullptr; // (the CG loop adds its control block's flag: sbhip_cg.inc.h)
     h->push.timeoutTicks = 5000 * P2P_TICKS_PER_MS; // self-test: 5 s
     // self-test: SIX exchanges (three per parity of the alternating staging areas); in exchange `it` every rank
     // sends value(rank, it) in all its slots, so a block that still holds an earlier exchange's data is caught
@@ -511,6 +512,19 @@ static void halo_p2p_setup(sb_halo* h)
     on = agree(good);
     if (!on && good) snprintf(why, sizeof why, "the self-test failed on another rank");
     h->push.timeoutTicks = g.p2pTimeoutTicks;
+    // TEST HOOKS (tests/test_gpu_bench.py: a failure on one rank must end the others at once): SB_TEST_DROP_PUSH_RANK=r with
+    // SB_TEST_DROP_PUSH_AT=k makes rank r "forget" to announce its k-th halo exchange from now on; SB_TEST_HALO_TIMEOUT_MS bounds
+    // the halo waits separately from the all-reduce's (SB_P2P_TIMEOUT_MS), so that the test can tell who timed out
+    if (const char* dr = getenv("SB_TEST_DROP_PUSH_RANK")) {
+      const char* at = getenv("SB_TEST_DROP_PUSH_AT");
+      if (atoi(dr) == g.rank && at && atoll(at) > 0) {
+        h->push.dropSeq = h->seq + (unsigned long long)atoll(at);
+        fprintf(stderr, "sbhip: rank %d: SB_TEST_DROP_PUSH_RANK is set: halo exchange %llu will not be announced (test hook)\n", g.rank,
+            h->push.dropSeq);
+      }
+    }
+    if (const char* ht = getenv("SB_TEST_HALO_TIMEOUT_MS"))
+      if (atoll(ht) > 0) h->push.timeoutTicks = atoll(ht) * P2P_TICKS_PER_MS;
   }
   sb_free(dflag);
   if (!on) halo_p2p_release(h);

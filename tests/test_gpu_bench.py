@@ -124,6 +124,29 @@ def test_a_crash_in_the_peer_mapped_legs_still_yields_the_validated_line(gpu):
     assert "rank 1 exited with code 9" in d["degraded"]["why"] and d["degraded"]["exit_codes"]["1"] == 9
 
 
+def test_a_rank_whose_wait_runs_out_takes_the_others_with_it_at_once(gpu):
+    """a rank whose bounded wait runs out used to stop alone, and every peer then sat out its own 30 s in the
+    next all-reduce before reporting a misleading "contribution did not arrive".  Now the failing rank poisons what it would have
+    published (all-reduce slots, halo flags; kernels.hip.h: P2P_POISON) and every wait treats that as "the peer has failed".
+    Library test hooks: rank 2 does not announce one halo exchange of the peer-mapped pre-flight; halo waits are bounded at
+    400 ms, the all-reduce's at 60 s.  Rank 1 (waiting for rank 2's block) reports the cause, the others leave with it within
+    seconds -- and, the communicator's plane having been validated and timed first, the run still yields its degraded line."""
+    import time
+    ok, _ = run_bench("--gpus", "3", "--transport", "host", "--steps", "10", "--n", "32", "--no-cpu", "--no-push-inside-leg")
+    if ok["config"]["halo_exchange"] != "peer_mapped_push_pull":
+        pytest.skip("the peer-mapped halo did not come up on this box")
+    t0 = time.time()
+    d, err = run_bench("--gpus", "3", "--transport", "host", "--steps", "10", "--n", "32", "--no-cpu",
+                       env={"SB_TEST_DROP_PUSH_RANK": "2", "SB_TEST_DROP_PUSH_AT": "7", "SB_TEST_HALO_TIMEOUT_MS": "400",
+                            "SB_P2P_TIMEOUT_MS": "60000"})
+    took = time.time() - t0
+    assert took < 45, took  # (without the poison: 60 s in the next all-reduce)
+    assert "a neighbour's halo block did not arrive within 400 ms" in err  # the rank that saw the cause says so ...
+    assert "another rank reported a communication failure" in err          # ... the others say they stopped with it
+    assert "contribution to an in-kernel all-reduce did not arrive" not in err
+    assert d["value"] > 0 and "degraded" in d and d["config"]["data_plane"] == "host_staged_gloo data plane"
+
+
 def test_as_the_driver_launches_it_under_torch_distributed_run(gpu):
     """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`: every rank process supervises one worker"""
     import socket

@@ -69,6 +69,11 @@ def report(n, sigma):
     for i, nm in enumerate(names):
         d = q[:, i + 1] - q[:, i]
         print("  %-52s mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f us" % (nm, d.mean(), *np.percentile(d, [10, 50, 90])))
+    first = (q[:, 0] - t0) < 3.0  # tiles of the first round (dispatched while the chip is still filling) against the rest
+    for label, sel in (("first round (started < 3 us)", first), ("later tiles", ~first)):
+        if sel.sum():
+            print("  %s: %d tiles; " % (label, int(sel.sum())) + ", ".join("%s %.2f" % (nm.split("(")[0].replace("->", "").strip()[:24], (q[sel, i + 1] - q[sel, i]).mean())
+                                                                        for i, nm in enumerate(names)) + "; life %.2f us" % (q[sel, 6] - q[sel, 0]).mean())
     life = q[:, 6] - q[:, 0]
     print("  tile life                                            mean %.2f  p50 %.2f  p90 %.2f us" % (life.mean(), *np.percentile(life, [50, 90])))
     print("  start times: p25 %.2f p50 %.2f p75 %.2f p100 %.2f us" % tuple(np.percentile(np.sort(q[:, 0] - t0), [25, 50, 75, 100])))
