@@ -1,9 +1,7 @@
+# how the SpMV launch is timed inside the loop: {hipExtLaunchKernelGGL stamps, hipEventRecord brackets} x {events without / with the system fence}
 set -e
-mkdir -p gpurun_out/ext
-python bench.py --steps 60 --warmup 10 --no-cpu > gpurun_out/ext/ext.json 2> gpurun_out/ext/ext.err
-SB_SPMV_TIMING=record python bench.py --steps 60 --warmup 10 --no-cpu > gpurun_out/ext/record.json 2> gpurun_out/ext/record.err
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/ext/prof -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 10 --no-cpu --no-preflight --passes clean,events > $GRAFT_REPO_ROOT/gpurun_out/ext/prof.json 2> $GRAFT_REPO_ROOT/gpurun_out/ext/prof.err
-cd $GRAFT_REPO_ROOT
-for f in ext record prof; do python tools/show_bench.py gpurun_out/ext/$f.json | grep -E "it/s|roofline|reference"; done
-find gpurun_out/ext/prof -name "*kernel_stats.csv" | head -1 | xargs head -8
+for spec in "ext:0x20000000" "ext:0" "record:0x20000000" "record:0"; do
+  how=${spec%%:*}; fl=${spec#*:}
+  SB_SPMV_TIMING=$how SB_EVENT_FLAGS=$fl python bench.py --steps 60 --warmup 10 --no-cpu --no-preflight --passes clean,events 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; q=d['roofline_reference_layout']; print('$how flags $fl: %s %.2f us   %s %.2f us (frac %.3f)   clean %.0f it/s' % (r['kernel'], r['avg_launch_us'] if 'avg_launch_us' in r else r.get('launch_us',0), q['kernel'], q.get('avg_launch_us', q.get('launch_us',0)), q['frac'], d['value']))"
+done
