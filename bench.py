@@ -741,28 +741,37 @@ def run_rank(args):
         # that a failure of the peer-mapped plane on its first contact with real links still leaves a validated rate.
         checks, problems = [], []
         res_coll, degraded = None, None
+        coll_problems = []
         if second_plane:
             L.sb_comm_data_plane(0)
             if not args.no_preflight:
-                checks, problems = preflight(plane_name(0), prob)
-                if problems:
-                    fail_preflight(checks, problems, workload)
-            res_coll = measure(prob, [default])
-            launches_coll, collectives_coll = launches, collectives
-            L.sb_comm_data_plane(1)
-            coll_ms = gather(1e3 * res_coll[default]["t_mine"] / K)
-            provisional = compact_line(res_coll[default], 0, list(checks), coll_ms) if rank == 0 else None
-            if supervised:
+                checks, coll_problems = preflight(plane_name(0), prob)
+            if coll_problems:
+                # the communicator's plane gives wrong results here: nothing is timed on it, no checkpoint; the run goes on to the
+                # peer-mapped plane, whose own pre-flight decides whether there is a rate at all (both wrong: exit code 4)
                 if rank == 0:
-                    print(MARK + "provisional " + json.dumps(provisional), flush=True)
-                barrier()
-                print(MARK + "checkpoint", flush=True)
-            if os.environ.get("SB_BENCH_TEST_DIE_AFTER_CHECKPOINT") == str(rank):  # test hook: a crash in the peer-mapped legs
-                sys.stderr.write("bench: rank %d: SB_BENCH_TEST_DIE_AFTER_CHECKPOINT is set, exiting with code 9 (test hook)\n" % rank)
-                os._exit(9)
+                    for msg in coll_problems:
+                        sys.stderr.write("bench: PRE-FLIGHT FAILED on the communicator's data plane: %s\n" % msg)
+                L.sb_comm_data_plane(1)
+            else:
+                res_coll = measure(prob, [default])
+                launches_coll, collectives_coll = launches, collectives
+                L.sb_comm_data_plane(1)
+                coll_ms = gather(1e3 * res_coll[default]["t_mine"] / K)
+                provisional = compact_line(res_coll[default], 0, list(checks), coll_ms) if rank == 0 else None
+                if supervised:
+                    if rank == 0:
+                        print(MARK + "provisional " + json.dumps(provisional), flush=True)
+                    barrier()
+                    print(MARK + "checkpoint", flush=True)
+                if os.environ.get("SB_BENCH_TEST_DIE_AFTER_CHECKPOINT") == str(rank):  # test hook: a crash in the peer-mapped legs
+                    sys.stderr.write("bench: rank %d: SB_BENCH_TEST_DIE_AFTER_CHECKPOINT is set, exiting with code 9 (test hook)\n" % rank)
+                    os._exit(9)
         if not args.no_preflight:
             recs, bad = preflight(plane_name(1), prob)
             checks += recs
+            if bad and coll_problems:
+                fail_preflight(checks, coll_problems + bad, workload)
             if bad and second_plane:
                 # the peer-mapped plane gives WRONG results here, the communicator's plane passed: no rate from the former, the
                 # line is quoted on the latter and says so (exit code 0: a validated rate; the failure is in the line and on stderr)
@@ -863,7 +872,9 @@ def run_rank(args):
                 "cg_reference_oplist_bytes_per_iteration": cg_alg,
                 "ms_per_step_with_events": (1e3 * d["t_ev"] / K) if d["t_ev"] else None,
                 "phases_us": phase_table(d["phases"]),
-                "preflight": ({"ok": True, "checks": checks} if not args.no_preflight else {"ok": None, "skipped": "--no-preflight"}),
+                "preflight": ({"ok": not coll_problems, "checks": checks, **({"problems": coll_problems, "ok_on_the_plane_value_is_quoted_on": True}
+                                                                              if coll_problems else {})}
+                              if not args.no_preflight else {"ok": None, "skipped": "--no-preflight"}),
                 "compression": prob.pack_info(),
                 "device": L.sb_device_name().decode(),
                 "parity": {
@@ -936,7 +947,13 @@ def run_rank(args):
                             "GPU (rehearsals) keep each other's pushes off the CUs, so only a run with one rank per GPU can rank the two"}
             elif inside_problems:
                 out["push_inside"] = {"value": None, "preflight": {"ok": False, "problems": inside_problems, "checks": inside_checks}}
-            if res_coll is None and world > 1:
+            if coll_problems:
+                out["rccl_only"] = {"value": None, "preflight": {"ok": False, "problems": coll_problems},
+                                    "note": "the communicator's data plane failed its pre-flight: nothing was timed on it; `value` is the "
+                                            "peer-mapped plane's, which passed"}
+                out["degraded"] = {"why": "the communicator's data plane failed its pre-flight", "value_is_quoted_on": plane_name(1),
+                                   "problems": coll_problems}
+            elif res_coll is None and world > 1:
                 out["rccl_only"] = {"note": "not timed separately: " + (
                     "--no-rccl-leg" if args.no_rccl_leg else "the peer-mapped paths are off, `value` IS the communicator's data plane")}
         prob.free()

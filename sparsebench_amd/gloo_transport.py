@@ -9,6 +9,7 @@ tests/gpu_multirank_worker.py and by `bench.py --transport host` (rehearsal of t
 bench flow on one GPU); correct, not fast.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -71,6 +72,11 @@ def attach(L, H, dist, rank, size):
     def exchange(ctx, send_dev, outdeg, dests, scnt, sdsp, recv_dev, indeg, srcs, rcnt, rdsp):
         total = sum(scnt[i] for i in range(outdeg))
         sbuf = d2h(send_dev, total)
+        # TEST HOOK (bench.py's degraded completion the other way round, tests/test_gpu_bench.py): rank r's staged send / recv swaps
+        # its first two values -- wrong on the communicator's plane ONLY (the peer-mapped push does not come through here)
+        if os.environ.get("SB_TEST_CORRUPT_HOST_EXCHANGE") == str(rank) and total >= 2:
+            sbuf = sbuf.copy()
+            sbuf[0], sbuf[1] = sbuf[1], sbuf[0]
         reqs, bufs = [], []
         for i in range(outdeg):
             reqs.append(dist.isend(torch.from_numpy(sbuf[sdsp[i]:sdsp[i] + scnt[i]].copy()), dests[i]))

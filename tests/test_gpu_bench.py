@@ -115,6 +115,20 @@ def test_a_peer_mapped_plane_that_delivers_wrong_values_degrades_to_the_validate
     assert 0.3 < d["value"] / ok["rccl_only"]["value"] < 3.0
 
 
+def test_a_communicator_plane_that_delivers_wrong_values_leaves_the_peer_mapped_line(gpu):
+    """... and the other way round: SB_TEST_CORRUPT_HOST_EXCHANGE=1 makes rank 1's staged send / recv swap two values (the
+    peer-mapped push is untouched).  Nothing is timed on the communicator's plane, no checkpoint; the peer-mapped plane passes its
+    own pre-flight and carries `value`; the line says which plane failed.  Both wrong (SB_TEST_CORRUPT_HALO) stays exit code 4."""
+    d, err = run_bench("--gpus", "2", "--transport", "host", "--steps", "10", "--n", "32", "--no-cpu", "--no-push-inside-leg",
+                       env={"SB_TEST_CORRUPT_HOST_EXCHANGE": "1"})
+    if d["config"]["halo_exchange"] != "peer_mapped_push_pull":
+        pytest.skip("the peer-mapped halo did not come up on this box: `value` IS the communicator's plane (and rc would be 4)")
+    assert d["value"] > 0 and d["rccl_only"]["value"] is None and d["rccl_only"]["preflight"]["problems"]
+    assert d["degraded"]["value_is_quoted_on"] == "peer-mapped data plane" and "PRE-FLIGHT FAILED on the communicator's data plane" in err
+    pf = d["preflight"]
+    assert pf["ok"] is False and pf["ok_on_the_plane_value_is_quoted_on"] is True and [c["ok"] for c in pf["checks"]] == [False, True]
+
+
 def test_a_crash_in_the_peer_mapped_legs_still_yields_the_validated_line(gpu):
     d, err = run_bench("--gpus", "2", "--transport", "host", "--steps", "10", "--n", "32", "--no-cpu",
                        env={"SB_BENCH_TEST_DIE_AFTER_CHECKPOINT": "1"})
