@@ -1013,7 +1013,7 @@ def run_rank(args):
                 "cg_iterations_per_s": K / d["t_clean"], "ms_per_step": 1e3 * d["t_clean"] / K,
                 "fill": (prob.nnzTrue / prob.nElems) if fmt == "scs" else 1.0,
                 "roofline": roofline_block(kern, d["moved"], d["alg"], d["spmv_us"], d["launches"], *tr),
-                "spmv_useful_GBs": (12.0 * prob.nnzTrue + 16.0 * prob.nr) / (d["spmv_us"] * 1e-6) / 1e9,
+                "spmv_useful_GBs": ((12.0 * prob.nnzTrue + 16.0 * prob.nr) / (d["spmv_us"] * 1e-6) / 1e9) if d["launches"] else None,
                 "separate_dot_pass": dot_pass, "phases_us": phase_table(d["phases"]),
                 "cg_frac_of_hbm_peak": cg_moved * (K / d["t_clean"]) / 1e9 / HBM_PEAK_GBS}
             if best is None or formats[name]["cg_iterations_per_s"] > formats[best]["cg_iterations_per_s"]:

@@ -681,6 +681,41 @@ __global__ __launch_bounds__(256) void dot_spans_k(uint32_t n, const double* a, 
   }
 }
 
+// dot(a, b) as LEVEL-1 values (one per 256 elements): the dot pass of the fused loop behind an SpMV kernel that cannot emit
+// p.Ap itself (native CRS, generic-C Sell-C-sigma).  A wave owns whole 256-groups, as in cg_update_r_k below: same additions in the
+// same order as dot_spans_k<0> followed by level1(), a quarter of the values for the scalar step -- and level-1 values are what
+// lets that step ride in the r update (cg_update_r_k<1>).
+__global__ __launch_bounds__(1024) void dot_l1_k(uint32_t n, const double* __restrict__ a, const double* __restrict__ b,
+    double* __restrict__ l1out, const int* __restrict__ stop)
+{
+  const uint32_t lane    = threadIdx.x & 63u;
+  const uint32_t nGroups = (n + 255u) >> 8;
+  const uint32_t nWaves  = gridDim.x * (blockDim.x >> 6);
+  if (stop && *stop) return;
+  auto combine = [&](double t0, double t1) { // halves of t0: q0, q1; of t1: q2, q3
+    const double q0 = lane_value<0>(t0), q1 = lane_value<32>(t0), q2 = lane_value<0>(t1), q3 = lane_value<32>(t1);
+    return ((q0 + q1) + q2) + q3;
+  };
+  for (uint32_t gI = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); gI < nGroups; gI += nWaves) {
+    double t[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const uint32_t e = gI * 256u + (uint32_t)h * 128u + lane * 2u;
+      double tt        = 0.0;
+      if (e + 1 < n) {
+        const double2 av = *reinterpret_cast<const double2*>(a + e);
+        const double2 bv = *reinterpret_cast<const double2*>(b + e);
+        tt               = av.x * bv.x + av.y * bv.y;
+      } else if (e < n) {
+        tt = a[e] * b[e] + 0.0;
+      }
+      t[h] = butterfly32(tt);
+    }
+    const double v = combine(t[0], t[1]);
+    if (lane == 0) l1out[gI] = v;
+  }
+}
+
 // r -= alpha Ap and r.r of the fused loop (src/CGSolver.c:128 + :112), once per CG iteration.  A wave owns whole
 // 256-groups (two adjacent spans), so it forms the group's LEVEL-1 value ((q0 + q1) + q2) + q3 in registers and the
 // scalar step that follows reads n/256 doubles instead of n/64 (reduce_final_1024, l1).  The first group's loads go

@@ -413,7 +413,8 @@ template <int MODE> static void scalar_launch(sb_cg* s, int defer_x, const doubl
 }
 
 // 1: the SpMV's fused dot wrote LEVEL-1 values of p.Ap (one per 256 rows), 0: level-0 partials (dot pass, lab kernels)
-static int pAp_is_level1(const sb_cg* s) { return spmv_can_fuse_dot(s) && spmv_dot_kind(s->A) == 2 ? 1 : 0; }
+// (fused loop behind a kernel without a dot of its own: the dot pass is dot_l1_k)
+static int pAp_is_level1(const sb_cg* s) { return spmv_can_fuse_dot(s) ? (spmv_dot_kind(s->A) == 2 ? 1 : 0) : (s->fused && s->nr ? 1 : 0); }
 
 // The scalar steps inside their consumers' launches (kernels.hip.h: cg_update_r_k<ALPHA>, cg_update_p<BETA>): EVERY workgroup of
 // the consumer takes the step itself -- nobody waits for anybody --, workgroup 0 records it.  Returns the mode: 0 the separate
@@ -578,7 +579,12 @@ static void spmv_and_pAp(sb_cg* s, const int* stop)
     spmv_time_end(s);
     mark(s, R_SPMVM);
     phase_mark(s, PH_SPMV);
-    launch_dot_spans(0, n, s->p, s->Ap, nullptr, nullptr, s->S, s->partials, stop);
+    if (s->fused && n) { // level-1 values straight away (pAp_is_level1): a quarter of the bytes for the step, which can then ride in the r update
+      const uint32_t nGroups = (n + 255u) >> 8;
+      hipLaunchKernelGGL(dot_l1_k, dim3(std::max(1u, std::min((uint32_t)g.prop.multiProcessorCount * 2u, (nGroups + 15u) / 16u))), dim3(1024), 0,
+          g.stream, n, (const double*)s->p, (const double*)s->Ap, s->partials, stop);
+      HIP_CHECK(hipGetLastError());
+    } else launch_dot_spans(0, n, s->p, s->Ap, nullptr, nullptr, s->S, s->partials, stop);
     phase_mark(s, PH_DOT_PASS);
   }
 }
