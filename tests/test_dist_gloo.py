@@ -1,4 +1,4 @@
-"""N > 1 on CPU: world_size-2 (and 4) gloo runs of the product's partition / halo-plan
+"""N > 1 on CPU: world_size-2 (and 4; 8 = the rank count of BASELINE configs[3]) gloo runs of the product's partition / halo-plan
 code with torch.distributed as the setup exchange, checked against the oracle and the
 MPI reference histories (see tests/dist_worker.py)."""
 import os
@@ -19,7 +19,7 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("case,size", [("hpcg", 2), ("klein", 2), ("hpcg", 4), ("distribute", 2), ("distribute", 3), ("distribute", 4),
+@pytest.mark.parametrize("case,size", [("hpcg", 2), ("klein", 2), ("hpcg", 4), ("hpcg", 8), ("distribute", 2), ("distribute", 3), ("distribute", 4),
                                        ("irregular", 2), ("irregular", 3)])
 def test_partition_and_halo_plan_multi_process(case, size):
     env = dict(os.environ, OMP_NUM_THREADS="1")
