@@ -1,4 +1,5 @@
 # A/B: two tiles per workgroup in the fused SpMV (second tile's header prefetched) against one (SB_FUSEP_TILES_PER_WG)
+# -- needs tools/lab/two_tiles_per_workgroup_experiment.patch applied (the switch does not exist in the product)
 set -e
 python -m pytest tests/test_gpu_cg.py -x -q -m gpu > gpurun_out/tpw_tests.log 2>&1 || { tail -30 gpurun_out/tpw_tests.log; exit 1; }
 tail -2 gpurun_out/tpw_tests.log
