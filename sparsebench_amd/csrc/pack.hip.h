@@ -804,9 +804,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(72))) /* see sp
   double t[WB];
   const bool mappedWin = MASKED && (flags & PAT_MAPPED_WINDOW) != 0u; // uniform per workgroup
   if (mappedWin) { // slot by slot through the map
-    const uint16_t* mp = slotMap + (size_t)hidx * mapStride + threadIdx.x;
+    // (distinct maps stored once behind a header -> map table: sbhip_matrix.inc.h; the index is a uniform load that is back with the header)
+    const uint32_t mStr = mapStride & 0xFFFu, mOff = (mapStride >> 12) * 256u;
+    const uint32_t mIdx = mOff ? reinterpret_cast<const uint32_t*>(slotMap)[hidx] : hidx;
+    const uint16_t* mp  = slotMap + mOff + (size_t)mIdx * mStr + threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < WB; k++) dmap[k] = mp[min((uint32_t)k * 256u, mapStride - 256u)];
+    for (int k = 0; k < WB; k++) dmap[k] = mp[min((uint32_t)k * 256u, mStr - 256u)];
 #pragma unroll
     for (int k = 0; k < WB; k++) t[k] = xcol(field(12 + min(k, 17)) + dmap[k]);
   } else if (simple) { // segment by segment: entry i of segment s -> slot first_s + i
@@ -1159,12 +1162,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(72))) void spmv
   // (the second half's map entries ride in the high halves of the first half's registers: 8 live registers instead of 15)
   uint32_t dmap[MAPPED ? H1 : 1];
   if (MAPPED) {
-    const uint16_t* mp = slotMap + (size_t)hidx * mapStride + threadIdx.x;
+    // (distinct maps stored once behind a header -> map table: sbhip_matrix.inc.h; the index is a uniform load that is back with the header)
+    const uint32_t mStr = mapStride & 0xFFFu, mOff = (mapStride >> 12) * 256u;
+    const uint32_t mIdx = mOff ? reinterpret_cast<const uint32_t*>(slotMap)[hidx] : hidx;
+    const uint16_t* mp  = slotMap + mOff + (size_t)mIdx * mStr + threadIdx.x;
     uint32_t lo[H1], hi[H1];
 #pragma unroll
     for (int k = 0; k < H1; k++) {
-      lo[k] = mp[min((uint32_t)k * 256u, mapStride - 256u)];
-      hi[k] = k + H1 < WB ? (uint32_t)mp[min((uint32_t)(k + H1) * 256u, mapStride - 256u)] : 0u;
+      lo[k] = mp[min((uint32_t)k * 256u, mStr - 256u)];
+      hi[k] = k + H1 < WB ? (uint32_t)mp[min((uint32_t)(k + H1) * 256u, mStr - 256u)] : 0u;
     }
 #pragma unroll
     for (int k = 0; k < H1; k++) dmap[k] = lo[k] | (hi[k] << 16);

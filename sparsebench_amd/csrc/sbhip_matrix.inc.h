@@ -896,11 +896,50 @@ static bool build_masked_mapped(sb_matrix* m, uint32_t cpt, const uint32_t* chun
     return false;
   }
   m->mOwnsTables = true, m->mSegs = dSegs, m->mWindow = maxWin, m->mMapStride = P.mapStride;
-  { // the map in HEADER order (interior tiles first): the kernel fetches it next to the header, before it knows the tile
-    std::vector<uint16_t> byHdr(P.slotMap.size());
-    for (uint32_t hI = 0; hI < P.nTiles; hI++)
-      memcpy(byHdr.data() + (size_t)hI * P.mapStride, P.slotMap.data() + (size_t)m->mTileOfHdr[hI] * P.mapStride, (size_t)P.mapStride * sizeof(uint16_t));
-    m->mSlotMap = (uint16_t*)upload(byHdr.data(), byHdr.size() * sizeof(uint16_t));
+  { // The maps are relative to their 256-slot blocks' bases (header words), so tiles whose windows look alike up to a shift
+    // hold the SAME map -- on a stencil matrix all but the boundary tiles.  Store every distinct map once, and a table
+    // header -> map in front of them: [u32 index per header, padded to 256 entries of 16 bits][distinct maps]; the table's
+    // length in units of 256 map entries rides in the high bits of mMapStride (the stride itself is < 4096).  At HPCG 128^3
+    // that is a few hundred KB instead of 18.9 MB of map per SpMV, and the map fetch finds its lines in L2.  Where hardly
+    // anything repeats (SB_PACK_MAP_DEDUP=0 forces that) the table is left out and header h's map is map h, as before.
+    const size_t ms = P.mapStride;
+    std::vector<uint32_t> idxOfHdr(P.nTiles);
+    std::vector<const uint16_t*> uniq;
+    std::unordered_multimap<uint64_t, uint32_t> seen;
+    for (uint32_t hI = 0; hI < P.nTiles; hI++) {
+      const uint16_t* mp = P.slotMap.data() + (size_t)m->mTileOfHdr[hI] * ms;
+      uint64_t h = 1469598103934665603ull;
+      for (size_t i = 0; i < ms; i++) h = (h ^ mp[i]) * 1099511628211ull;
+      uint32_t found = 0xFFFFFFFFu;
+      auto range = seen.equal_range(h);
+      for (auto it = range.first; it != range.second; ++it)
+        if (memcmp(uniq[it->second], mp, ms * sizeof(uint16_t)) == 0) { found = it->second; break; }
+      if (found == 0xFFFFFFFFu) {
+        found = (uint32_t)uniq.size();
+        uniq.push_back(mp);
+        seen.emplace(h, found);
+      }
+      idxOfHdr[hI] = found;
+    }
+    const char* de    = getenv("SB_PACK_MAP_DEDUP");
+    const bool dedup  = !(de && atoi(de) == 0) && uniq.size() * 4 <= (size_t)P.nTiles * 3;
+    const size_t offU = dedup ? ((size_t)P.nTiles * 2 + 255) / 256 : 0; // table length in units of 256 u16
+    if (offU >= (1u << 20)) SB_FATAL("slot-map table too long");
+    const size_t nMaps = dedup ? uniq.size() : (size_t)P.nTiles;
+    std::vector<uint16_t> buf(offU * 256 + nMaps * ms);
+    if (dedup) {
+      memcpy(buf.data(), idxOfHdr.data(), (size_t)P.nTiles * sizeof(uint32_t));
+      for (size_t u = 0; u < nMaps; u++) memcpy(buf.data() + offU * 256 + u * ms, uniq[u], ms * sizeof(uint16_t));
+    } else {
+      for (uint32_t hI = 0; hI < P.nTiles; hI++)
+        memcpy(buf.data() + (size_t)hI * ms, P.slotMap.data() + (size_t)m->mTileOfHdr[hI] * ms, ms * sizeof(uint16_t));
+    }
+    m->mSlotMap   = (uint16_t*)upload(buf.data(), buf.size() * sizeof(uint16_t));
+    m->mMapStride = (uint32_t)ms | ((uint32_t)offU << 12);
+    m->mBytes += 2.0 * ms * (double)nMaps + 512.0 * offU - 2.0 * ms * (double)P.nTiles; // (build_masked counted one map per tile)
+    if (getenv("SB_PACK_REPORT"))
+      fprintf(stderr, "sbhip pack: slot maps: %zu distinct of %u tiles (%zu entries each)%s\n", uniq.size(), P.nTiles, ms,
+          dedup ? ": stored once, indexed per header" : ": stored per tile");
   }
   m->mTileOfHdr.clear(), m->mTileOfHdr.shrink_to_fit();
   sb_free(P.dRowBase), sb_free(P.dTileClass); // (mClassDict stays)
