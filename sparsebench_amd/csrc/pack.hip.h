@@ -1141,6 +1141,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(72))) void spmv
     const u32x2 h2  = *(lane < (uint32_t)PAT_STOP_LANE ? hp + lane : reinterpret_cast<const u32x2*>(&S->stop));
     hvx = h2.x, hvy = h2.y;
   }
+  // slot k of this thread: which column it holds (mapped windows).  The map's index (uniform, a 16 KB table) and the map's loads
+  // (distinct maps stored once: 31 KB at HPCG 128^3, sbhip_matrix.inc.h) leave together with the header's load, so the map is
+  // there when the header is: 28.5-28.6 against 28.7-29.0 us per launch, and 53 instead of 63 VGPRs (two builds, same box,
+  // alternating).  (With one map per tile -- 21 MB per launch out of the Infinity Cache -- the early fetch cost registers and
+  // bought nothing: rounds 2-3.)
+  // (the second half's map entries ride in the high halves of the first half's registers: 8 live registers instead of 15)
+  uint32_t dmapE[MAPPED ? H1 : 1];
+  if (MAPPED) {
+    const uint32_t mStr = mapStride & 0xFFFu, mOff = (mapStride >> 12) * 256u;
+    const uint32_t mIdx = mOff ? reinterpret_cast<const uint32_t*>(slotMap)[hidx] : hidx;
+    const uint16_t* mp  = slotMap + mOff + (size_t)mIdx * mStr + threadIdx.x;
+    uint32_t lo[H1], hi[H1];
+#pragma unroll
+    for (int k = 0; k < H1; k++) {
+      lo[k] = mp[min((uint32_t)k * 256u, mStr - 256u)];
+      hi[k] = k + H1 < WB ? (uint32_t)mp[min((uint32_t)(k + H1) * 256u, mStr - 256u)] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < H1; k++) dmapE[k] = lo[k] | (hi[k] << 16);
+  }
   // the step's scalars (uniform: scalar loads, back with the header)
   const double beta  = which ? 0.0 : S->beta; // k = 1: p = r + 0.0 * r (:109), the host passes pold = r
   const double alpha = S->alpha;
@@ -1158,23 +1178,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(72))) void spmv
     }
     __syncthreads();
   }
-  // slot k of this thread: which column it holds, where it goes, whether it exists
-  // (the second half's map entries ride in the high halves of the first half's registers: 8 live registers instead of 15)
+  // where slot k goes, whether it exists
   uint32_t dmap[MAPPED ? H1 : 1];
-  if (MAPPED) {
-    // (distinct maps stored once behind a header -> map table: sbhip_matrix.inc.h; the index is a uniform load that is back with the header)
-    const uint32_t mStr = mapStride & 0xFFFu, mOff = (mapStride >> 12) * 256u;
-    const uint32_t mIdx = mOff ? reinterpret_cast<const uint32_t*>(slotMap)[hidx] : hidx;
-    const uint16_t* mp  = slotMap + mOff + (size_t)mIdx * mStr + threadIdx.x;
-    uint32_t lo[H1], hi[H1];
 #pragma unroll
-    for (int k = 0; k < H1; k++) {
-      lo[k] = mp[min((uint32_t)k * 256u, mStr - 256u)];
-      hi[k] = k + H1 < WB ? (uint32_t)mp[min((uint32_t)(k + H1) * 256u, mStr - 256u)] : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < H1; k++) dmap[k] = lo[k] | (hi[k] << 16);
-  }
+  for (int k = 0; k < (MAPPED ? H1 : 1); k++) dmap[k] = dmapE[k];
   auto col_of = [&](int k) -> uint32_t {
     if (MAPPED) return field(12 + min(k, 17)) + (k < H1 ? dmap[MAPPED ? k : 0] & 0xFFFFu : dmap[MAPPED ? k - H1 : 0] >> 16);
     const int sI = k < 3 * LONG ? k / LONG : 3 + (k - 3 * LONG);
