@@ -288,7 +288,9 @@ static void build_lds_windows(sb_matrix* m, const uint32_t* chunkPtr, const uint
     const double reuse = sumWin ? (double)sumElems / (double)sumWin : 0.0;
     const double run   = segs.empty() ? 0.0 : (double)sumWin / (double)segs.size();
     const char* force  = getenv("SB_PACK_LDS");
-    const bool want    = force ? atoi(force) != 0 : (reuse >= 3.0 && run >= 32.0);
+    // (reuse: 2.75, not 3 -- a 27-point stencil whose x-lines are exactly one 4-chunk tile long, n = 256, sits at 2.98 with these
+    //  tiles and at 4.5 with the 8-chunk tiles of level 6, which this decision gates; the run length keeps irregular matrices out)
+    const bool want    = force ? atoi(force) != 0 : (reuse >= 2.75 && run >= 32.0);
     if (!want) return;
   }
   m->tileSegPtr = (uint32_t*)upload(segPtr.data(), segPtr.size() * sizeof(uint32_t));

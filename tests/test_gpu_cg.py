@@ -319,6 +319,29 @@ def test_full_size_properties_128(gpu, golden_1rank):
     assert long["err"] < 1e-6 and abs(long["x"] - 1.0).max() == long["err"]
 
 
+def test_a_brick_eight_times_the_benchmark_size_256(gpu):
+    """256^3 per GPU (16.8 M rows, 453 M stored elements: past the Infinity Cache, every chunk's columns span more than 16 bits,
+    an x-line is exactly one 4-chunk tile): the library must still choose the masked row programs with the p update inside the
+    SpMV (round 3: the LDS-window decision used to stop one step short at exactly this shape), and the loop on them must give the
+    bits of the loop on the reference-layout kernel; closed-form r.r0 and p.Ap1 (exact integers at any size)."""
+    from sparsebench_amd import knownanswers as ka
+    n = 256
+    p = hostapi.Problem("generate", n, n, n, fmt="scs", Cc=64, sigma=256)
+    assert p.pack_info()["mode"] == 5
+    cg = hostapi.CG(p)
+    assert cg.fuse_p() == 1 and cg.launches_per_body() == 3
+    cg.solve(12, 0.0)
+    rr, pap = cg.history()
+    assert rr[0] == ka.hpcg_rr0(n, n, n) and pap[0] == ka.hpcg_pAp1(n, n, n)
+    cg.free()
+    assert p.use_packed(0) == 0
+    cg0 = hostapi.CG(p)
+    cg0.solve(12, 0.0)
+    rr0, pap0 = cg0.history()
+    assert np.array_equal(rr, rr0) and np.array_equal(pap, pap0)
+    cg0.free(), p.free()
+
+
 def test_multi_rank_kernel_sequence_through_rccl_on_one_gpu(gpu, monkeypatch):
     """SB_FORCE_RCCL=1 attaches a 1-rank RCCL communicator: the CG then takes the
     multi-rank path (local reduce -> ncclAllReduce on the stream -> scalar update) and

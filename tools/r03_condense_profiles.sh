@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 H=$(cat gpurun_out/r03_source_hash.txt)
-for f in r03_bench_n1_128_scs_sigma256 r03_bench_n1_as_the_driver_types_it r03_bench_n1_128_scs_sigma256_five_launches r03_bench_n1_128_scs_sigma256_separate_alpha_step r03_bench_n1_128_scs_sigma1 r03_bench_n1_64_scs_sigma1 r03_bench_n1_128_crs r03_bench_irregular r03_bench_rehearsal_n2 r03_bench_rehearsal_n3 r03_bench_rehearsal_n4 r03_bench_rehearsal_n6 r03_bench_rehearsal_n2_128 r03_bench_rehearsal_n4_128; do cp gpurun_out/$f.json profiles/$f.json; done
+for f in r03_bench_n1_128_scs_sigma256 r03_bench_n1_as_the_driver_types_it r03_bench_n1_128_scs_sigma256_five_launches r03_bench_n1_128_scs_sigma256_separate_alpha_step r03_bench_n1_128_scs_sigma1 r03_bench_n1_64_scs_sigma1 r03_bench_n1_256_scs_sigma256 r03_bench_n1_128_crs r03_bench_irregular r03_bench_rehearsal_n2 r03_bench_rehearsal_n3 r03_bench_rehearsal_n4 r03_bench_rehearsal_n6 r03_bench_rehearsal_n2_128 r03_bench_rehearsal_n4_128; do cp gpurun_out/$f.json profiles/$f.json; done
 cp gpurun_out/r03_clean_default_kernel_stats.csv gpurun_out/r03_clean_reflayout_kernel_stats.csv profiles/
 ( echo "# default loop (bench.py --no-cpu --steps 240 --no-preflight --passes clean)"; cat gpurun_out/r03_clean_default_trace_summary.txt; echo; echo "# reference-layout loop (... --pack-mode 0)"; cat gpurun_out/r03_clean_reflayout_trace_summary.txt ) > profiles/r03_clean_loop_trace_summary.txt
 cp "$(find gpurun_out/prof/r03_hpcg128/kt -name '*kernel_stats.csv')" profiles/r03_hpcg128_kernel_stats.csv

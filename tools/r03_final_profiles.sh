@@ -12,6 +12,7 @@ python3 bench.py --fuse-p 0 --fuse-alpha 0 --fuse-beta 0 --no-cpu > gpurun_out/r
 python3 bench.py --fuse-alpha 0 --no-cpu > gpurun_out/r03_bench_n1_128_scs_sigma256_separate_alpha_step.json 2>> gpurun_out/r03_bench_n1.err; echo "bench fuse-alpha 0 rc=$?"
 python3 bench.py --sigma 1 --no-cpu > gpurun_out/r03_bench_n1_128_scs_sigma1.json 2>> gpurun_out/r03_bench_n1.err; echo "bench sigma 1 rc=$?"
 python3 bench.py --n 64 --sigma 1 > gpurun_out/r03_bench_n1_64_scs_sigma1.json 2>> gpurun_out/r03_bench_n1.err; echo "bench 64 rc=$?"
+python3 bench.py --n 256 --steps 40 --warmup 5 --no-cpu > gpurun_out/r03_bench_n1_256_scs_sigma256.json 2>> gpurun_out/r03_bench_n1.err; echo "bench 256 rc=$?"
 python3 bench.py --fmt crs --no-cpu > gpurun_out/r03_bench_n1_128_crs.json 2>> gpurun_out/r03_bench_n1.err; echo "bench crs rc=$?"
 python3 bench.py --workload irregular --irr-sigmas 1,256 --steps 120 > gpurun_out/r03_bench_irregular.json 2>> gpurun_out/r03_bench_n1.err; echo "bench irregular rc=$?"
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
