@@ -220,6 +220,8 @@ def test_single_gpu_line_has_the_contract_keys(gpu):
         assert rl["phases_us"]["spmv"] > d["phases_us"]["spmv"] and "p_update" in rl["phases_us"]  # (that loop keeps its separate p update)
     # (the breakdown is taken with an event after every launch, ~2-3 us each: its sum brackets the clean step time from above)
     assert d["preflight"]["ok"] and d["timed_repeats"] == 9 and 1e3 * d["ms_per_step"] <= sum(d["phases_us"].values()) <= 3e3 * d["ms_per_step"]
+    # informational: the same clean loop over thousands of steps in one go (a K-step window is a short burst between host-side pauses)
+    assert d["sustained"]["steps"] == 4800 and d["sustained"]["value"] > 0.8 * d["value"] and d["sustained"]["reference_layout_value"] > 0
     cb = d["cpu_baseline"]
     assert cb and cb["value"] > 0 and cb["cores"] >= 1 and cb["nproc"] >= cb["cores"] and cb["kind"] in ("reference", "port")
     check_fractions(d)
