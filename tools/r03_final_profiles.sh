@@ -18,17 +18,17 @@ python3 bench.py --workload irregular --irr-sigmas 1,256 --steps 120 > gpurun_ou
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 for spec in "default:" "reflayout:--pack-mode 0"; do
   tag=${spec%%:*}; extra=${spec#*:}
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/r03_clean_$tag -o r1 -- python3 bench.py --no-cpu --steps 240 --no-preflight --passes clean $extra > gpurun_out/prof/r03_clean_$tag.json 2> gpurun_out/prof/r03_clean_$tag.err || echo "clean trace $tag failed"
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/r03_clean_$tag -o r1 -- python3 bench.py --no-cpu --steps 240 --no-preflight --passes clean --sustained-steps 0 $extra > gpurun_out/prof/r03_clean_$tag.json 2> gpurun_out/prof/r03_clean_$tag.err || echo "clean trace $tag failed"
   f=$(find gpurun_out/prof/r03_clean_$tag -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r03_clean_${tag}_kernel_stats.csv
   t=$(find gpurun_out/prof/r03_clean_$tag -name "*kernel_trace.csv" | head -1); python3 tools/scalar_anatomy.py trace "$t" > gpurun_out/r03_clean_${tag}_trace_summary.txt
   rm -rf gpurun_out/prof/r03_clean_$tag
 done
-tools/prof_run.sh r03_hpcg128 bench.py --no-cpu --steps 60 --warmup 5 --no-preflight
+tools/prof_run.sh r03_hpcg128 bench.py --no-cpu --steps 60 --warmup 5 --no-preflight --sustained-steps 0
 # the native CRS kernel (equal nonzero windows) inside CG, and the irregular stand-in: FETCH / WRITE passes only
 for spec in "r03_hpcg128_crs:--fmt crs --pack-mode 0 --steps 40" "r03_irregular:--workload irregular --irr-sigmas 1,256 --steps 40"; do
   tag=${spec%%:*}; extra=${spec#*:}; out=gpurun_out/prof/$tag; mkdir -p $out
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o r1 -- python3 bench.py --no-cpu --warmup 5 --no-preflight --passes clean,events $extra > $out/kt.log 2>&1 || echo "kt $tag failed"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o r1 -- python3 bench.py --no-cpu --warmup 5 --no-preflight --passes clean,events $extra > $out/fetch.log 2>&1 || echo "fetch $tag failed"
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o r1 -- python3 bench.py --no-cpu --warmup 5 --no-preflight --passes clean,events $extra > $out/write.log 2>&1 || echo "write $tag failed"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o r1 -- python3 bench.py --no-cpu --warmup 5 --no-preflight --passes clean,events --sustained-steps 0 $extra > $out/kt.log 2>&1 || echo "kt $tag failed"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o r1 -- python3 bench.py --no-cpu --warmup 5 --no-preflight --passes clean,events --sustained-steps 0 $extra > $out/fetch.log 2>&1 || echo "fetch $tag failed"
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o r1 -- python3 bench.py --no-cpu --warmup 5 --no-preflight --passes clean,events --sustained-steps 0 $extra > $out/write.log 2>&1 || echo "write $tag failed"
 done
 echo done
