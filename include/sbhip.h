@@ -52,12 +52,29 @@ void sb_h2d(void* dev, const void* host, size_t bytes); /* synchronous */
 void sb_d2h(void* host, const void* dev, size_t bytes); /* synchronous */
 void sb_d2d(void* dst, const void* src, size_t bytes);  /* stream-ordered */
 int sb_is_device_ptr(const void* p);
+/* replaces: allocate() AS THE DRIVER USES IT, src/allocate.c:12-36 + src/main.c:205-211 -- vectors the caller fills with host
+ * loops and then hands to spMVM.  Memory in HBM that the CPU can store to (fine-grained device memory through the PCIe BAR) and
+ * kernels read in place; NULL where the one-time probe says this box cannot do that (sb_host_visible_reason() tells why either
+ * way; SPARSEBENCH_ALLOCATE=host switches it off).  sb_is_device_ptr() is 1 for it; free with sb_free(). */
+void* sb_malloc_host_visible(size_t bytes);
+const char* sb_host_visible_reason(void);
+void* sb_malloc_pinned_host(size_t bytes); /* fallback: pinned host memory (staged by spMVM / waxpby / ddot); NULL on failure */
+void sb_free_pinned_host(void* p);
+/* host <-> device copies made through sb_h2d / sb_d2h so far: {h2d calls, h2d bytes, d2h calls, d2h bytes} */
+void sb_copy_counters(uint64_t out[4]);
 
 /* stream-ordered timing (PROFILE macro, src/profiler.h:18-21, needs completion) */
 void* sb_event_create(void);
 void sb_event_record(void* ev);
 float sb_event_elapsed_ms(void* start, void* stop); /* synchronises on stop */
 void sb_event_destroy(void* ev);
+/* replaces: the PROFILE macro's host clock, src/profiler.h:18-21 -- a region (tag 0..7) bracketed by two events on the layer's
+ * stream, nothing waits inside the caller's loop; sb_region_seconds() waits for what is outstanding and returns the accumulated
+ * DEVICE time of the tag and how many regions were recorded. */
+void sb_region_begin(int tag);
+void sb_region_end(int tag);
+double sb_region_seconds(int tag, uint64_t* count);
+void sb_region_reset(void);
 
 /* ---- matrix upload (device side of convertMatrix, src/matrix.h:57) -------- */
 /* CRS: src/CRSMatrix.h:9-16.  Arrays are host pointers, copied to HBM. */

@@ -220,7 +220,14 @@ void sbh_init_matrix(Comm* c, Parameter* p, GMatrix* m);
 /* commDistributeMatrix for a driver in which EVERY rank has read the file: keeps this rank's rows in place */
 void sbh_distribute_local(Comm* c, MMMatrix* m, MMMatrix* mLocal);
 void sbh_write_bin_matrix(Comm* c, char* mtxFilename);
-void* allocate(size_t alignment, size_t bytesize); /* src/allocate.h:9 (host memory) */
+/* src/allocate.h:9 -- the allocation hook.  With a device up, requests >= 64 KiB come back as memory that lives in HBM, that
+ * host loops can store to and that spMVM / waxpby / ddot use in place (src/main.c:205-215 then times the kernel, not staging);
+ * see host/sbh_base.c.  sbh_allocate_kind(): what the last request got -- 0 plain host, 1 device-resident and host-visible,
+ * 2 pinned host.  sbh_alloc_host(): always plain host memory (what the library's own host-side arrays use). */
+void* allocate(size_t alignment, size_t bytesize);
+void* sbh_alloc_host(size_t alignment, size_t bytesize);
+int sbh_allocate_kind(void);
+void sbh_allocate_free(void* p);
 double getTimeStamp(void);                          /* src/timing.h:8 */
 double getTimeResolution(void);                     /* src/timing.h:9 */
 
@@ -250,12 +257,19 @@ void ddot(const CG_UINT n, const CG_FLOAT* restrict x, const CG_FLOAT* restrict 
 /* ---- profiler: src/profiler.h:10-30 --------------------------------------------------- */
 typedef enum { WAXPBY = 0, SPMVM, DDOT, COMM, NUMREGIONS } regions;
 extern double _t[NUMREGIONS];
+/* The reference reads the host clock around a synchronous CPU call (src/profiler.h:18-21).  Here `call` is a stream-ordered
+ * launch: the region is bracketed by two device events (sbh_region_begin / _end), nothing waits inside the caller's loop, and
+ * profilerPrint() reports the accumulated DEVICE time of every tag that recorded regions (the host-side enqueue time is still
+ * added to _t[tag], as the reference does, and is what the table falls back to for a tag without regions). */
 #define PROFILE(tag, call)                                                     \
   ts = getTimeStamp();                                                         \
+  sbh_region_begin(tag);                                                       \
   call;                                                                        \
-  sbh_profile_sync();                                                          \
+  sbh_region_end(tag);                                                         \
   _t[tag] += (getTimeStamp() - ts);
-void sbh_profile_sync(void); /* PROFILE needs the call complete (src/profiler.h:18-21) */
+void sbh_region_begin(int tag);
+void sbh_region_end(int tag);
+void sbh_profile_sync(void); /* waits for the layer's stream (callers that time with the host clock themselves) */
 void profilerInit(size_t* facFlops, size_t* facWords);
 void profilerPrint(Comm* c, int iterations);
 void profilerFinalize(void);

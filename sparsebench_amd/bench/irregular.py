@@ -1,0 +1,100 @@
+"""bench.py, workload `irregular` (BASELINE.json configs[4]): irregular-nnz stress, CRS vs Sell-C-sigma on one GPU.  SuiteSparse
+Flan_1565 is not available offline; the matrix is the committed stand-in of host/sbh_irregular.c (80^3 nodes: 1 536 000 rows, 94 M
+nonzeros, 3x3-block FE rows of 3..99 entries, 5 % far couplings).  Every format streams its reference layout (no mirror applies), so
+every roofline block here is on SURVEY 8d's algorithmic bytes.
+
+Pre-flight: the stand-in at 24^3 nodes against the history the REFERENCE ITSELF produced on it (its own reader, convertMatrix and
+solveCG on the matrix exported as .mtx; tests/golden/cg_hist_irregular_ref.json): every format within north_star's 1e-12 of it, CRS
+and Sell-64-1 (same row order, same dot order) with identical bits."""
+import json
+import os
+
+from .context import quiet_stdout
+from .line import HBM_PEAK_GBS, ROOT, kernel_name, phase_table, pmc_traffic, roofline_block, vector_bytes
+from .preflight import fail_preflight
+from .timing import measure
+
+
+def run(ctx, cpu):
+    import numpy as np
+    from sparsebench_amd import hostapi
+    a, L, K, W = ctx.args, ctx.L, ctx.K, ctx.W
+    if ctx.world != 1:
+        raise SystemExit("bench: --workload irregular is a one-GPU workload (configs[4])")
+    n = a.n if a.n > 0 else 80
+    formats = {}
+    best = None
+    specs = [("crs", 1)] + [("scs", s) for s in a.irr_sigmas]
+    irr_checks, irr_problems = [], []
+    if not a.no_preflight:
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "cg_hist_irregular_ref.json")))["irregular24"]
+        except (OSError, ValueError, KeyError):
+            gold = None
+        if gold:
+            ref_rr, ref_pap = np.array([float(v) for v in gold["rr"]]), np.array([float(v) for v in gold["pAp"]])
+            first = None
+            for fmt, sigma in specs:
+                with quiet_stdout():
+                    pr = hostapi.Problem("irregular", 24, 24, 24, fmt=fmt, Cc=64, sigma=sigma)
+                cgp = ctx.new_cg(pr, graph=False)
+                kk = cgp.solve(gold["itermax"], 0.0)
+                rr, pap = cgp.history()
+                cgp.free()
+                pr.free()
+                label = "irregular 24^3 nodes, %s sigma %d" % (fmt, sigma)
+                same_len = len(rr) == len(ref_rr) and len(pap) == len(ref_pap)
+                dev = float(max((np.abs(rr - ref_rr) / ref_rr).max(), (np.abs(pap - ref_pap) / ref_pap).max())) if same_len else float("inf")
+                rec = {"case": label, "k": kk, "max_rel_deviation_from_the_reference_history": dev, "ok": kk == gold["k"] and dev <= 1e-12}
+                if sigma == 1:
+                    if first is None:
+                        first = (rr, pap)
+                    rec["same_bits_as_crs"] = bool(np.array_equal(rr, first[0]) and np.array_equal(pap, first[1]))
+                    rec["ok"] = rec["ok"] and rec["same_bits_as_crs"]
+                irr_checks.append(rec)
+                if not rec["ok"]:
+                    irr_problems.append("%s: k = %d (reference %d), deviation %.3g from the reference's history (bound 1e-12)" % (label, kk, gold["k"], dev))
+            if irr_problems:
+                fail_preflight(ctx, irr_checks, irr_problems, "irregular_fe_%d^3_nodes" % n)
+    meta = {}
+    for fmt, sigma in specs:
+        with quiet_stdout():
+            prob = hostapi.Problem("irregular", n, n, n, fmt=fmt, Cc=64, sigma=sigma)
+        default = prob.pack_info()["mode"]
+        res = measure(ctx, prob, [default])
+        d = res[default]
+        name = "crs" if fmt == "crs" else "scs_C64_sigma%d" % sigma
+        workload = "irregular_fe_%d^3_nodes_%s" % (n, name)
+        kern = kernel_name(fmt, default, bool(L.sb_matrix_crs_kernel(prob.matrix)))
+        tr = pmc_traffic(workload, kern)
+        # (a native CRS kernel without the fused p.Ap adds a dot pass over p and Ap: 16 B/row)
+        dot_pass = bool(d["phases"] and "dot_pass" in d["phases"])
+        cg_moved = d["moved"] + vector_bytes(prob.nr, d["vector_phase"]) + (16.0 * prob.nr if dot_pass else 0.0)
+        it = K / d["t_clean"]
+        formats[name] = {
+            "cg_iterations_per_s": it, "ms_per_step": 1e3 * d["t_clean"] / K,
+            "fill": (prob.nnzTrue / prob.nElems) if fmt == "scs" else 1.0,
+            "roofline": roofline_block(kern, d["alg"], d["alg"], d["spmv_us"], d["launches"], *tr),
+            "spmv_useful_GBs": ((12.0 * prob.nnzTrue + 16.0 * prob.nr) / (d["spmv_us"] * 1e-6) / 1e9) if d["launches"] else None,
+            "separate_dot_pass": dot_pass, "launches_per_iteration": d["launches_per_body"], "phases_us": phase_table(d["phases"]),
+            "cg_frac_of_roofline": it * (96.0 * prob.nr + d["alg"]) / 1e9 / HBM_PEAK_GBS,
+            "cg_frac_of_hbm_peak_on_moved_bytes": cg_moved * it / 1e9 / HBM_PEAK_GBS}
+        if best is None or formats[name]["cg_iterations_per_s"] > formats[best]["cg_iterations_per_s"]:
+            best = name
+            meta = {"rows": prob.nr, "nnz": prob.nnzTrue}
+        prob.free()
+    b = formats[best]
+    return {
+        "metric": "cg_iterations_per_s", "value": b["cg_iterations_per_s"], "ok": True,
+        "unit": "iterations/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": b["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "irregular_fe_%d^3_nodes (SuiteSparse Flan_1565 not available offline; committed stand-in "
+                               "host/sbh_irregular.c), best format: %s" % (n, best),
+                   "rows_per_gpu": meta["rows"], "nnz_per_gpu": meta["nnz"], "index_type": "u32",
+                   "parallelism": "1d_block_row_x1", "library": ctx.version},
+        "timed_repeats": ctx.repeats,
+        "roofline": b["roofline"], "cg_frac_of_roofline": b["cg_frac_of_roofline"], "formats": formats,
+        "device": L.sb_device_name().decode(),
+        "preflight": ({"ok": True, "checks": irr_checks} if irr_checks else {"ok": None, "skipped": "--no-preflight or no golden"}),
+        "cpu_baseline": cpu,
+    }

@@ -33,6 +33,8 @@ SYMBOLS = [
     "sb_comm_data_plane", "sb_comm_data_plane_selected", "sb_comm_rccl_info", "sb_cg_phase_timing", "sb_cg_phase_ms",
     "sb_comm_halo_push_inside", "sb_lab_build", "sb_cg_collectives_per_body",
     "sb_cg_set_fuse_p", "sb_cg_fuse_p", "sb_cg_set_fuse_alpha", "sb_cg_set_fuse_beta",
+    "sb_malloc_host_visible", "sb_host_visible_reason", "sb_malloc_pinned_host", "sb_free_pinned_host", "sb_copy_counters",
+    "sb_region_begin", "sb_region_end", "sb_region_seconds", "sb_region_reset",
 ]
 
 _lib = None
@@ -149,6 +151,15 @@ def load():
         "sb_comm_rccl_info": (C.c_int, [C.POINTER(C.c_int)]),
         "sb_cg_phase_timing": (None, [vp, C.c_int]),
         "sb_cg_phase_ms": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+        "sb_malloc_host_visible": (vp, [C.c_size_t]),
+        "sb_host_visible_reason": (C.c_char_p, []),
+        "sb_malloc_pinned_host": (vp, [C.c_size_t]),
+        "sb_free_pinned_host": (None, [vp]),
+        "sb_copy_counters": (None, [C.POINTER(C.c_uint64)]),
+        "sb_region_begin": (None, [C.c_int]),
+        "sb_region_end": (None, [C.c_int]),
+        "sb_region_seconds": (C.c_double, [C.c_int, C.POINTER(C.c_uint64)]),
+        "sb_region_reset": (None, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

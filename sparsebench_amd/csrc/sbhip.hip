@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <math.h>
+#include <setjmp.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -281,6 +283,7 @@ struct sb_cg {
   double* pbuf[2] = { nullptr, nullptr };
   int fusepPlan = -1; // 1: the loop uses spmv_prog_fusep, 0: not, -1: not decided yet
   int fusepWant = -1; // sb_cg_set_fuse_p: 1 / 0, -1: SB_FUSE_P or the library default
+  int fusepLatched = -1; // the plan of the solve that is running (set by sb_cg_start, cleared by sb_cg_finish)
   int fuseAlphaWant = -1; // sb_cg_set_fuse_alpha: 1 / 0, -1: SB_FUSE_ALPHA or the library default (on)
   int fuseBetaWant  = -1; // sb_cg_set_fuse_beta
   int betaFold      = 0;  // 1 / 2: the last enqueued body left its beta step to the next p update (fold mode)
@@ -406,17 +409,201 @@ void sb_memset(void* dev, int byte, size_t bytes)
   need_init();
   HIP_CHECK(hipMemsetAsync(dev, byte, bytes, g.stream));
 }
+// Host <-> device copies through this layer are counted (sb_copy_counters): the drop-in's claim "the reference's own -t spmv loop
+// moves nothing over PCIe"  is asserted on these counters by tests/test_gpu_dropin.py.
+static uint64_t g_copies[4]; // h2d calls, h2d bytes, d2h calls, d2h bytes
 void sb_h2d(void* dev, const void* host, size_t bytes)
 {
   need_init();
+  g_copies[0]++, g_copies[1] += bytes;
   HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, g.stream));
   HIP_CHECK(hipStreamSynchronize(g.stream));
 }
 void sb_d2h(void* host, const void* dev, size_t bytes)
 {
   need_init();
+  g_copies[2]++, g_copies[3] += bytes;
   HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, g.stream));
   HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+void sb_copy_counters(uint64_t out[4])
+{
+  for (int i = 0; i < 4; i++) out[i] = g_copies[i];
+}
+
+// ---- host-visible device memory: the reference's allocation hook -------------------------------------------------------
+// src/allocate.c:12-36 hands out the vectors that src/main.c:205-211 fills with HOST loops and then passes to spMVM
+// (src/main.c:213-215).  For that loop to time the kernel and not PCIe staging, allocate() (host/sbh_base.c) asks here for
+// memory that lives in HBM, that the CPU can store to through the PCIe BAR, and that kernels read in place: fine-grained
+// device memory (hipDeviceMallocFinegrained: device accesses stay coherent with the host's stores; a coarse-grained hipMalloc
+// region may be served from a stale L2 line after a host store).  Whether the CPU can really reach it is PROBED once, with the
+// store guarded by a SIGSEGV / SIGBUS handler: a box without a large BAR answers with a fault, not with an error code.
+static struct HostVisible {
+  int probed = 0, ok = 0;
+  char reason[320] = "not probed yet";
+} hv;
+static sigjmp_buf hv_jmp;
+static void hv_fault(int) { siglongjmp(hv_jmp, 1); }
+
+static bool hv_guarded_cpu_roundtrip(volatile uint64_t* p, uint64_t v)
+{
+  struct sigaction sa, oldSegv, oldBus;
+  memset(&sa, 0, sizeof sa);
+  sa.sa_handler = hv_fault;
+  sigemptyset(&sa.sa_mask);
+  sigaction(SIGSEGV, &sa, &oldSegv);
+  sigaction(SIGBUS, &sa, &oldBus);
+  bool ok = false;
+  if (sigsetjmp(hv_jmp, 1) == 0) {
+    p[0] = v;
+    __sync_synchronize();
+    ok = p[0] == v;
+  }
+  sigaction(SIGSEGV, &oldSegv, nullptr);
+  sigaction(SIGBUS, &oldBus, nullptr);
+  return ok;
+}
+
+static void hv_probe(void)
+{
+  hv.probed = 1;
+  const char* off = getenv("SPARSEBENCH_ALLOCATE");
+  if (off && strcmp(off, "host") == 0) {
+    snprintf(hv.reason, sizeof hv.reason, "SPARSEBENCH_ALLOCATE=host: allocate() hands out plain host memory (vectors are staged)");
+    return;
+  }
+  int largeBar = 0;
+  if (hipDeviceGetAttribute(&largeBar, hipDeviceAttributeIsLargeBar, g.device) != hipSuccess) (void)hipGetLastError();
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained);
+  if (e != hipSuccess || !p) {
+    (void)hipGetLastError();
+    snprintf(hv.reason, sizeof hv.reason, "hipExtMallocWithFlags(hipDeviceMallocFinegrained) failed: %s (large BAR attribute: %d)",
+        hipGetErrorString(e), largeBar);
+    return;
+  }
+  const uint64_t v = 0x5b5b00c0ffee1234ull;
+  if (!hv_guarded_cpu_roundtrip((volatile uint64_t*)p, v)) {
+    snprintf(hv.reason, sizeof hv.reason, "the CPU cannot store to fine-grained device memory on this box (fault or wrong read-back; "
+        "large BAR attribute: %d)", largeBar);
+    (void)hipFree(p);
+    return;
+  }
+  // the device must see the host's store, and the host the device's
+  uint64_t back = 0;
+  bool ok = hipMemcpy(&back, p, 8, hipMemcpyDeviceToHost) == hipSuccess && back == v;
+  ok = ok && hipMemset(p, 0x3c, 8) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+       *(volatile uint64_t*)p == 0x3c3c3c3c3c3c3c3cull;
+  (void)hipFree(p);
+  if (!ok) {
+    (void)hipGetLastError();
+    snprintf(hv.reason, sizeof hv.reason, "host stores to fine-grained device memory did not reach the device (or the other way round)");
+    return;
+  }
+  hv.ok = 1;
+  snprintf(hv.reason, sizeof hv.reason, "fine-grained device memory, CPU-writable through the PCIe BAR (probed: host store -> device "
+      "read, device store -> host read; large BAR attribute: %d)", largeBar);
+}
+
+void* sb_malloc_host_visible(size_t bytes)
+{
+  need_init();
+  if (!hv.probed) hv_probe();
+  if (!hv.ok) return nullptr;
+  void* p = nullptr;
+  if (hipExtMallocWithFlags(&p, bytes ? bytes : 8, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+const char* sb_host_visible_reason(void)
+{
+  if (g.init && !hv.probed) hv_probe();
+  return hv.reason;
+}
+void* sb_malloc_pinned_host(size_t bytes)
+{
+  need_init();
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+void sb_free_pinned_host(void* p)
+{
+  if (p) HIP_CHECK(hipHostFree(p));
+}
+
+// ---- device-timed profile regions (PROFILE macro, src/profiler.h:18-21) ---------------------------------------------------
+// The reference's PROFILE reads the host clock around a synchronous CPU call.  Here the call is a stream-ordered launch: a
+// region is bracketed by two events on the layer's stream (no system-scope fence), nothing waits inside the loop, and the
+// accumulated DEVICE time is read when the table is printed ("time regions with hipEvents and fill _t[] afterwards").
+struct RegionTimer {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> open; // recorded, not yet read
+  std::vector<hipEvent_t> spare;
+  double seconds = 0.0;
+  uint64_t count = 0;
+  hipEvent_t cur = nullptr;
+};
+static RegionTimer g_regions[8];
+static hipEvent_t region_event(RegionTimer& r)
+{
+  if (!r.spare.empty()) {
+    hipEvent_t e = r.spare.back();
+    r.spare.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
+  return e;
+}
+static void region_drain(RegionTimer& r, size_t keep)
+{
+  while (r.open.size() > keep) {
+    auto pr = r.open.front();
+    float ms = 0.f;
+    HIP_CHECK(hipEventSynchronize(pr.second));
+    HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
+    r.seconds += 1e-3 * ms;
+    r.spare.push_back(pr.first), r.spare.push_back(pr.second);
+    r.open.erase(r.open.begin());
+  }
+}
+void sb_region_begin(int tag)
+{
+  if (!g.init || tag < 0 || tag >= 8) return;
+  RegionTimer& r = g_regions[tag];
+  r.cur          = region_event(r);
+  HIP_CHECK(hipEventRecord(r.cur, g.stream));
+}
+void sb_region_end(int tag)
+{
+  if (!g.init || tag < 0 || tag >= 8 || !g_regions[tag].cur) return;
+  RegionTimer& r = g_regions[tag];
+  hipEvent_t e   = region_event(r);
+  HIP_CHECK(hipEventRecord(e, g.stream));
+  r.open.push_back({ r.cur, e });
+  r.cur = nullptr;
+  r.count++;
+  if (r.open.size() >= 512) region_drain(r, 256); // (the oldest are long complete: no stall in practice)
+}
+double sb_region_seconds(int tag, uint64_t* count)
+{
+  if (tag < 0 || tag >= 8) return 0.0;
+  RegionTimer& r = g_regions[tag];
+  if (g.init) region_drain(r, 0);
+  if (count) *count = r.count;
+  return r.seconds;
+}
+void sb_region_reset(void)
+{
+  for (auto& r : g_regions) {
+    if (g.init) region_drain(r, 0);
+    r.seconds = 0.0, r.count = 0;
+  }
 }
 void sb_d2d(void* dst, const void* src, size_t bytes)
 {

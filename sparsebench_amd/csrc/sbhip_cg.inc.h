@@ -71,10 +71,7 @@ sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host, con
     HIP_CHECK(hipStreamSynchronize(g.stream));
   }
   s->S         = (CgScalars*)sb_malloc(sizeof(CgScalars));
-  if (halo && halo->p2p) { // the push kernels of this loop also look at its control block's failure flag (poisoning: kernels.hip.h)
-    halo->push.p2pErr = &s->S->p2p_error;
-    HIP_CHECK(hipMemcpy(halo->dPush, &halo->push, sizeof halo->push, hipMemcpyHostToDevice));
-  }
+  HIP_CHECK(hipMemset(s->S, 0, sizeof(CgScalars))); // never an uninitialised failure flag (sb_cg_start points the push kernels at it)
   s->nPartials = (m->nr + 255) / 256;
   // level-0 partials: 4 per 256 rows; the tail beyond the last chunk stays +0.0
   s->partials = (double*)sb_malloc((4 * (size_t)s->nPartials + 4) * sizeof(double));
@@ -213,6 +210,11 @@ static bool spmv_can_fuse_dot(const sb_cg* s);
 // SB_FUSE_P=0 keeps the separate p update.
 static bool fusep_plan(sb_cg* s)
 {
+  // Inside a solve the answer is the one sb_cg_start latched: the fused path keeps p double-buffered and picks the
+  // buffer from the body count, the in-place path does not -- a body of the other kind in the middle of a solve (the matrix's
+  // kernel mode or the wish changed between two sb_cg_run_iters pieces) would read the wrong p.  Such a change takes effect with
+  // the next sb_cg_start.
+  if (s->started && s->fusepLatched >= 0) return s->fusepLatched > 0;
   if (s->fusepPlan < 0) { // (the wish is decided once; whether it applies follows the matrix's kernel mode and the data plane)
     const char* env = getenv("SB_FUSE_P");
     s->fusepPlan    = (s->fusepWant >= 0 ? s->fusepWant != 0 : env ? atoi(env) != 0 : SB_FUSE_P_DEFAULT) ? 1 : 0;
@@ -792,6 +794,16 @@ void sb_cg_start(sb_cg* s, int itermax, double eps)
 {
   need_init();
   const uint32_t n = s->nr;
+  s->started      = false;
+  s->fusepLatched = fusep_plan(s) ? 1 : 0; // decided once per solve (fusep_plan)
+  if (s->halo && s->halo->p2p && s->halo->push.p2pErr != &s->S->p2p_error) {
+    // the push kernels of THIS solve also look at its control block's failure flag (poisoning: kernels.hip.h).  Set per solve,
+    // not at create: the plan is shared, and a second sb_cg on the same halo must not redirect a running loop's pushes to a
+    // control block that is not in use
+    s->halo->push.p2pErr = &s->S->p2p_error;
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+    HIP_CHECK(hipMemcpy(s->halo->dPush, &s->halo->push, sizeof s->halo->push, hipMemcpyHostToDevice));
+  }
   ensure_hist(s, itermax + 2);
   s->timing  = !s->fused; // the reference-shaped op list is the one that gets the region table
   s->evUsed  = 0;
@@ -891,7 +903,8 @@ int sb_cg_finish(sb_cg* s)
       if (s->evRegion[i] >= 0) s->region_ms[s->evRegion[i]] += ms;
     }
   }
-  s->timing = false;
+  s->timing       = false;
+  s->fusepLatched = -1; // the solve is over: the next sb_cg_start decides anew
   return h.iters + 1; // the value of k when the reference's for loop exits (:107,:140)
 }
 

@@ -60,13 +60,13 @@ void matrixBinWrite(GMatrix* m, Comm* c, char* filename)
   put(totals, sizeof(unsigned int), 2, f, filename);
   put(m->rowPtr, sizeof(CG_UINT), (size_t)m->totalNr + 1, f, filename);
   if (fp64) {
-    Entry* out = (Entry*)allocate(ARRAY_ALIGNMENT, ((size_t)m->nnz + 1) * sizeof(Entry));
+    Entry* out = (Entry*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)m->nnz + 1) * sizeof(Entry));
     memset(out, 0, ((size_t)m->nnz + 1) * sizeof(Entry)); /* padding bytes of Entry are written too */
     for (size_t i = 0; i < m->nnz; i++) out[i].col = m->entries[i].col, out[i].val = m->entries[i].val;
     put(out, sizeof(Entry), m->nnz, f, filename);
     free(out);
   } else {
-    FEntry* out = (FEntry*)allocate(ARRAY_ALIGNMENT, ((size_t)m->nnz + 1) * sizeof(FEntry));
+    FEntry* out = (FEntry*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)m->nnz + 1) * sizeof(FEntry));
     for (size_t i = 0; i < m->nnz; i++) out[i].col = (unsigned int)m->entries[i].col, out[i].val = (float)m->entries[i].val;
     put(out, sizeof(FEntry), m->nnz, f, filename);
     free(out);
@@ -104,7 +104,7 @@ void matrixBinRead(GMatrix* m, Comm* c, char* filename)
   m->stopRow  = (CG_UINT)(cursor - 1);
 
   const long rowPtrAt = BMX_HEADERSIZE + 2 * (long)sizeof(unsigned int);
-  m->rowPtr = (CG_UINT*)allocate(ARRAY_ALIGNMENT, ((size_t)numRows + 1) * sizeof(CG_UINT));
+  m->rowPtr = (CG_UINT*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)numRows + 1) * sizeof(CG_UINT));
   if (fseek(f, rowPtrAt + (long)startRow * (long)sizeof(unsigned int), SEEK_SET) != 0) die("seek failed", filename);
   get(m->rowPtr, sizeof(CG_UINT), (size_t)numRows + 1, f, filename);
   const CG_UINT entryOffset = m->rowPtr[0];
@@ -113,12 +113,12 @@ void matrixBinRead(GMatrix* m, Comm* c, char* filename)
   m->nnz = m->rowPtr[numRows];
 
   const long entriesAt = rowPtrAt + ((long)totalNr + 1) * (long)sizeof(unsigned int);
-  m->entries = (Entry*)allocate(ARRAY_ALIGNMENT, ((size_t)m->nnz + 1) * sizeof(Entry));
+  m->entries = (Entry*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)m->nnz + 1) * sizeof(Entry));
   if (fp64) {
     if (fseek(f, entriesAt + (long)entryOffset * (long)sizeof(Entry), SEEK_SET) != 0) die("seek failed", filename);
     get(m->entries, sizeof(Entry), m->nnz, f, filename);
   } else {
-    FEntry* in = (FEntry*)allocate(ARRAY_ALIGNMENT, ((size_t)m->nnz + 1) * sizeof(FEntry));
+    FEntry* in = (FEntry*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)m->nnz + 1) * sizeof(FEntry));
     if (fseek(f, entriesAt + (long)entryOffset * (long)sizeof(FEntry), SEEK_SET) != 0) die("seek failed", filename);
     get(in, sizeof(FEntry), m->nnz, f, filename);
     for (size_t i = 0; i < m->nnz; i++) m->entries[i].col = (CG_UINT)in[i].col, m->entries[i].val = (CG_FLOAT)in[i].val;

@@ -111,6 +111,14 @@ void commFinalize(Comm* c)
   c->elementsToSend = c->sources = c->recvCounts = c->rdispls = NULL;
   c->destinations = c->sendCounts = c->sdispls = NULL;
   c->externalGlobal = NULL;
+  if (getenv("SB_COPY_REPORT") && sb_is_initialized()) {
+    /* what crossed PCIe through this layer during the run, and what the allocation hook handed out (tests/test_gpu_dropin.py) */
+    uint64_t n[4];
+    sb_copy_counters(n);
+    fprintf(stderr, "sbhip copies: h2d %llu calls %llu bytes, d2h %llu calls %llu bytes; allocate(): last kind %d (%s)\n",
+        (unsigned long long)n[0], (unsigned long long)n[1], (unsigned long long)n[2], (unsigned long long)n[3],
+        sbh_allocate_kind(), sb_host_visible_reason());
+  }
   sb_finalize();
 }
 

@@ -13,7 +13,7 @@
 
 static CG_UINT* row_lengths(const GMatrix* im)
 {
-  CG_UINT* n = (CG_UINT*)allocate(ARRAY_ALIGNMENT, ((size_t)im->nr + 1) * sizeof(CG_UINT));
+  CG_UINT* n = (CG_UINT*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)im->nr + 1) * sizeof(CG_UINT));
   for (CG_UINT i = 0; i < im->nr; i++) n[i] = im->rowPtr[i + 1] - im->rowPtr[i];
   return n;
 }
@@ -25,9 +25,9 @@ void sbh_layout_crs(CRSMatrix* m, GMatrix* im)
   m->totalNr = im->totalNr, m->totalNnz = im->totalNnz;
   m->nr = im->nr, m->nc = im->nc, m->nnz = im->nnz;
   const size_t stored = im->rowPtr[im->nr];
-  m->rowPtr = (CG_UINT*)allocate(ARRAY_ALIGNMENT, ((size_t)im->nr + 1) * sizeof(CG_UINT));
-  m->colInd = (CG_UINT*)allocate(ARRAY_ALIGNMENT, (stored + 1) * sizeof(CG_UINT));
-  m->val    = (CG_FLOAT*)allocate(ARRAY_ALIGNMENT, (stored + 1) * sizeof(CG_FLOAT));
+  m->rowPtr = (CG_UINT*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)im->nr + 1) * sizeof(CG_UINT));
+  m->colInd = (CG_UINT*)sbh_alloc_host(ARRAY_ALIGNMENT, (stored + 1) * sizeof(CG_UINT));
+  m->val    = (CG_FLOAT*)sbh_alloc_host(ARRAY_ALIGNMENT, (stored + 1) * sizeof(CG_FLOAT));
   memcpy(m->rowPtr, im->rowPtr, ((size_t)im->nr + 1) * sizeof(CG_UINT));
 #pragma omp parallel for schedule(static)
   for (long k = 0; k < (long)stored; k++) {
@@ -68,14 +68,14 @@ void sbh_layout_scs(SCSMatrix* m, GMatrix* im)
   m->nrPadded      = m->nChunks * C;
   const CG_UINT np = m->nrPadded;
 
-  CG_UINT* len = (CG_UINT*)allocate(ARRAY_ALIGNMENT, ((size_t)np + 1) * sizeof(CG_UINT));
+  CG_UINT* len = (CG_UINT*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)np + 1) * sizeof(CG_UINT));
   CG_UINT maxLen = 0;
   for (CG_UINT i = 0; i < np; i++) {
     len[i] = i < nr ? im->rowPtr[i + 1] - im->rowPtr[i] : 0;
     if (len[i] > maxLen) maxLen = len[i];
   }
   /* sortedRow[q] = original (padded) row at sorted position q */
-  CG_UINT* sortedRow = (CG_UINT*)allocate(ARRAY_ALIGNMENT, ((size_t)np + 1) * sizeof(CG_UINT));
+  CG_UINT* sortedRow = (CG_UINT*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)np + 1) * sizeof(CG_UINT));
   if (sigma == 1) {
     for (CG_UINT i = 0; i < np; i++) sortedRow[i] = i;
   } else {
@@ -90,8 +90,8 @@ void sbh_layout_scs(SCSMatrix* m, GMatrix* im)
     free(bucket);
   }
 
-  m->chunkLens = (CG_UINT*)allocate(ARRAY_ALIGNMENT, ((size_t)m->nChunks + 1) * sizeof(CG_UINT));
-  m->chunkPtr  = (CG_UINT*)allocate(ARRAY_ALIGNMENT, ((size_t)m->nChunks + 1) * sizeof(CG_UINT));
+  m->chunkLens = (CG_UINT*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)m->nChunks + 1) * sizeof(CG_UINT));
+  m->chunkPtr  = (CG_UINT*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)m->nChunks + 1) * sizeof(CG_UINT));
   size_t total = 0;
   for (CG_UINT c = 0; c < m->nChunks; c++) {
     CG_UINT width = 0;
@@ -108,16 +108,16 @@ void sbh_layout_scs(SCSMatrix* m, GMatrix* im)
   m->nElems               = (CG_UINT)total;
   m->chunkPtr[m->nChunks] = (CG_UINT)total;
 
-  m->oldToNewPerm = (CG_UINT*)allocate(ARRAY_ALIGNMENT, ((size_t)nr + 1) * sizeof(CG_UINT));
-  m->newToOldPerm = (CG_UINT*)allocate(ARRAY_ALIGNMENT, ((size_t)nr + 1) * sizeof(CG_UINT));
+  m->oldToNewPerm = (CG_UINT*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)nr + 1) * sizeof(CG_UINT));
+  m->newToOldPerm = (CG_UINT*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)nr + 1) * sizeof(CG_UINT));
   for (CG_UINT q = 0; q < np; q++)
     if (sortedRow[q] < nr) m->oldToNewPerm[sortedRow[q]] = q;
   /* padded rows (length 0) sort behind every real row of their window, and only the
    * last window has any, so real rows always land on positions < nr */
   for (CG_UINT i = 0; i < nr; i++) m->newToOldPerm[m->oldToNewPerm[i]] = i;
 
-  m->colInd = (CG_UINT*)allocate(ARRAY_ALIGNMENT, (total + 1) * sizeof(CG_UINT));
-  m->val    = (CG_FLOAT*)allocate(ARRAY_ALIGNMENT, (total + 1) * sizeof(CG_FLOAT));
+  m->colInd = (CG_UINT*)sbh_alloc_host(ARRAY_ALIGNMENT, (total + 1) * sizeof(CG_UINT));
+  m->val    = (CG_FLOAT*)sbh_alloc_host(ARRAY_ALIGNMENT, (total + 1) * sizeof(CG_FLOAT));
   memset(m->colInd, 0, (total + 1) * sizeof(CG_UINT));
   memset(m->val, 0, (total + 1) * sizeof(CG_FLOAT)); /* all-zero bits == 0.0 */
 #pragma omp parallel for schedule(static)

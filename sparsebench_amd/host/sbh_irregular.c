@@ -161,7 +161,7 @@ void sbh_matrix_generate_irregular(GMatrix* m, Parameter* p, int rank, int size)
   const uint64_t base = totalNr / (uint64_t)size, extra = totalNr % (uint64_t)size;
   const uint64_t first = (uint64_t)rank * base + ((uint64_t)rank < extra ? (uint64_t)rank : extra);
   const uint64_t nr    = base + ((uint64_t)rank < extra ? 1u : 0u);
-  m->rowPtr = (CG_UINT*)allocate(ARRAY_ALIGNMENT, (size_t)(nr + 1) * sizeof(CG_UINT));
+  m->rowPtr = (CG_UINT*)sbh_alloc_host(ARRAY_ALIGNMENT, (size_t)(nr + 1) * sizeof(CG_UINT));
 
   /* pass 1: row lengths (3 per neighbour node) */
 #pragma omp parallel for schedule(dynamic, 4096)
@@ -179,7 +179,7 @@ void sbh_matrix_generate_irregular(GMatrix* m, Parameter* p, int rank, int size)
     }
     m->rowPtr[r + 1] = (CG_UINT)total;
   }
-  m->entries = (Entry*)allocate(ARRAY_ALIGNMENT, ((size_t)total + 1) * sizeof(Entry));
+  m->entries = (Entry*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)total + 1) * sizeof(Entry));
 
   /* pass 2: entries.  Row = unknown i of node v; block (v, u) contributes columns 3u .. 3u+2. */
 #pragma omp parallel for schedule(dynamic, 4096)

@@ -77,7 +77,7 @@ int main(int argc, char** argv)
   c.y      = (double*)sb_malloc((size_t)g.nr * sizeof(double));
   c.w      = (double*)sb_malloc((size_t)g.nr * sizeof(double));
   c.scalar = (double*)sb_malloc(sizeof(double));
-  double* ones = (double*)allocate(ARRAY_ALIGNMENT, ((size_t)g.nc + 1) * sizeof(double));
+  double* ones = (double*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)g.nc + 1) * sizeof(double));
   for (CG_UINT i = 0; i < g.nc; i++) ones[i] = 1.0;
   sb_h2d(c.x, ones, (size_t)g.nc * sizeof(double));
   sb_h2d(c.w, ones, (size_t)g.nr * sizeof(double));

@@ -38,7 +38,7 @@ void matrixGenerate(GMatrix* m, Parameter* p, int rank, int size, bool use_7pt_s
     printf("%.2e total rows and %.2e nonzeros\n", (double)totalNr, (double)(27 * localNr));
   }
 
-  m->rowPtr = (CG_UINT*)allocate(ARRAY_ALIGNMENT, (size_t)(localNr + 1) * sizeof(CG_UINT));
+  m->rowPtr = (CG_UINT*)sbh_alloc_host(ARRAY_ALIGNMENT, (size_t)(localNr + 1) * sizeof(CG_UINT));
 
   /* pass 1: row lengths in closed form */
 #pragma omp parallel for schedule(static)
@@ -57,7 +57,7 @@ void matrixGenerate(GMatrix* m, Parameter* p, int rank, int size, bool use_7pt_s
   m->rowPtr[0] = 0;
   for (long i = 0; i < localNr; i++) m->rowPtr[i + 1] += m->rowPtr[i];
   const size_t nnzTrue = m->rowPtr[localNr];
-  m->entries           = (Entry*)allocate(ARRAY_ALIGNMENT, (nnzTrue + 1) * sizeof(Entry));
+  m->entries           = (Entry*)sbh_alloc_host(ARRAY_ALIGNMENT, (nnzTrue + 1) * sizeof(Entry));
 
   /* pass 2: fill */
 #pragma omp parallel for schedule(static)
@@ -148,7 +148,7 @@ void MMMatrixRead(MMMatrix* m, char* filename)
   printf("Read matrix %s with %d non zeroes and %d rows\n", filename, nz, M);
 
   const size_t cap = (size_t)nz * (symmetric ? 2 : 1);
-  MMEntry* a       = (MMEntry*)allocate(ARRAY_ALIGNMENT, (cap + 1) * sizeof(MMEntry));
+  MMEntry* a       = (MMEntry*)sbh_alloc_host(ARRAY_ALIGNMENT, (cap + 1) * sizeof(MMEntry));
   size_t n         = 0;
   for (int i = 0; i < nz; i++) {
     int r, c;
@@ -168,7 +168,7 @@ void MMMatrixRead(MMMatrix* m, char* filename)
   }
   fclose(f);
 
-  MMEntry* b = (MMEntry*)allocate(ARRAY_ALIGNMENT, (n + 1) * sizeof(MMEntry));
+  MMEntry* b = (MMEntry*)sbh_alloc_host(ARRAY_ALIGNMENT, (n + 1) * sizeof(MMEntry));
   counting_sort(a, b, n, N > M ? N : M, 0);
   counting_sort(b, a, n, M, 1);
   free(b);
@@ -189,8 +189,8 @@ void matrixConvertfromMM(MMMatrix* mm, GMatrix* m)
   m->nr       = (CG_UINT)mm->nr;
   m->nc       = (CG_UINT)mm->nr;
   m->nnz      = (CG_UINT)mm->nnz;
-  m->entries  = (Entry*)allocate(ARRAY_ALIGNMENT, ((size_t)m->nnz + 1) * sizeof(Entry));
-  m->rowPtr   = (CG_UINT*)allocate(ARRAY_ALIGNMENT, ((size_t)m->nr + 1) * sizeof(CG_UINT));
+  m->entries  = (Entry*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)m->nnz + 1) * sizeof(Entry));
+  m->rowPtr   = (CG_UINT*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)m->nr + 1) * sizeof(CG_UINT));
   memset(m->rowPtr, 0, ((size_t)m->nr + 1) * sizeof(CG_UINT));
   for (size_t i = 0; i < mm->count; i++) m->rowPtr[mm->entries[i].row - mm->startRow + 1]++;
   for (CG_UINT r = 0; r < m->nr; r++) m->rowPtr[r + 1] += m->rowPtr[r];

@@ -4,7 +4,7 @@
  *
  * Pointer convention: hot-path vectors live in HBM (sb_malloc).  A host pointer is
  * accepted everywhere the reference's own driver passes one (src/main.c:205-215
- * allocates x, y with allocate()): it is staged through HBM -- still computed on the
+ * allocates x, y with sbh_alloc_host()): it is staged through HBM -- still computed on the
  * GPU, just slower.  Nothing here computes on the CPU.
  */
 #define _GNU_SOURCE
@@ -21,6 +21,16 @@ double _t[NUMREGIONS];
 void sbh_profile_sync(void)
 {
   if (sb_is_initialized()) sb_sync();
+}
+
+/* PROFILE's device-timed regions (include/sparsebench/sparsebench.h); no-ops until a device is up */
+void sbh_region_begin(int tag)
+{
+  if (sb_is_initialized()) sb_region_begin(tag);
+}
+void sbh_region_end(int tag)
+{
+  if (sb_is_initialized()) sb_region_end(tag);
 }
 
 /* ---- staging helpers --------------------------------------------------------------- */
@@ -89,8 +99,8 @@ static int sbh_solve(Comm* comm, Parameter* param, void* dev_matrix, CG_UINT nr,
 {
   const int itermax    = param->itermax;
   const int generated  = strcmp(param->filename, "generate") == 0 || strcmp(param->filename, "generate7P") == 0;
-  double* b            = (double*)allocate(ARRAY_ALIGNMENT, ((size_t)nr + 1) * sizeof(double));
-  double* xexact       = generated ? (double*)allocate(ARRAY_ALIGNMENT, ((size_t)nr + 1) * sizeof(double)) : NULL;
+  double* b            = (double*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)nr + 1) * sizeof(double));
+  double* xexact       = generated ? (double*)sbh_alloc_host(ARRAY_ALIGNMENT, ((size_t)nr + 1) * sizeof(double)) : NULL;
   /* initVectors, src/CGSolver.c:25-36 */
   for (CG_UINT i = 0; i < nr; i++) {
     if (generated) {
@@ -167,6 +177,7 @@ void profilerInit(size_t* facFlops, size_t* facWords)
   /* per-iteration work: waxpby 3 words / 6 flops per row-factor, ddot 2 / 4, spMVM words
    * given whole and 2 flops per nonzero (src/profiler.c:19-22,35-41) */
   static const double w[NUMREGIONS] = { 3, 0, 2, 0 }, fl[NUMREGIONS] = { 6, 2, 4, 0 };
+  if (sb_is_initialized()) sb_region_reset();
   for (int i = 0; i < NUMREGIONS; i++) {
     _t[i]      = 0.0;
     g_words[i] = w[i] * (double)facWords[i];
@@ -183,7 +194,11 @@ void profilerPrint(Comm* c, int iterations)
   if (c->size > 1) printf("Function   Rate(MB/s)  Rate(MFlop/s)  Walltime(s)   [rank 0 of %d]\n", c->size);
   else printf("Function   Rate(MB/s)  Rate(MFlop/s)  Walltime(s)\n");
   for (int j = 0; j < NUMREGIONS - 1; j++) {
-    const double t = _t[j];
+    /* a tag whose calls went through PROFILE has device-timed regions: that is the time the kernels took (the host clock in
+     * _t[j] then only saw the enqueues) */
+    uint64_t regions = 0;
+    const double dev = sb_is_initialized() ? sb_region_seconds(j, &regions) : 0.0;
+    const double t   = regions > 0 ? dev : _t[j];
     printf("%s%11.2f %11.2f %11.2f\n", kLabel[j], t > 0.0 ? 1.0E-06 * g_words[j] * iterations / t : 0.0,
         t > 0.0 ? 1.0E-06 * g_flops[j] * iterations / t : 0.0, t);
   }

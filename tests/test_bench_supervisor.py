@@ -36,7 +36,7 @@ WORKER = textwrap.dedent('''
 def run(tmp_path, mode, n=3, env=None, torchrun_rank=None):
     w = tmp_path / "fake_worker.py"
     w.write_text(WORKER)
-    e = dict(os.environ, SB_BENCH_WORKER_SCRIPT=str(w), FAKE_MODE=mode, **(env or {}))
+    e = dict(os.environ, SB_BENCH_WORKER_SCRIPT=str(w), FAKE_MODE=mode, SB_BENCH_LOG_DIR=str(tmp_path / "logs"), **(env or {}))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SB_BENCH_RANK_PROCESS"):
         e.pop(k, None)
     if torchrun_rank is not None:  # as a rank process of torch.distributed.run: supervises ONE worker, environment inherited
@@ -57,6 +57,7 @@ def test_relays_exactly_one_line(tmp_path):
 def test_failure_before_the_checkpoint_is_an_error(tmp_path):
     rc, lines, err, dt = run(tmp_path, "die_early")
     assert rc == 5 and lines == [] and "rank 1 exited with code 5" in err and "boom before the checkpoint" in err and dt < 30
+    assert "the workers' stderr streams are in" in err
 
 
 def test_failure_behind_the_checkpoint_degrades_to_the_validated_plane(tmp_path):
@@ -66,6 +67,10 @@ def test_failure_behind_the_checkpoint_degrades_to_the_validated_plane(tmp_path)
     assert d["value"] == 1.0 and d["degraded"]["value_is_quoted_on"] == "rccl data plane"
     assert "rank 1 exited with code 9" in d["degraded"]["why"] and d["degraded"]["exit_codes"]["1"] == 9
     assert any("boom behind the checkpoint" in ln for ln in d["degraded"]["stderr_tail"]["1"]) and "DEGRADED" in err
+    # a degraded record is a finding, not a pass -- top-level flag, and every worker's WHOLE stderr in a file the line names
+    assert d["ok"] is False
+    log = d["degraded"]["stderr_files"]["1"]
+    assert log.startswith(str(tmp_path)) and "boom behind the checkpoint" in open(log).read() and "exit code 9" in open(log).read()
 
 
 def test_a_hang_behind_the_checkpoint_is_bounded(tmp_path):

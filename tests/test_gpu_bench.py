@@ -39,31 +39,40 @@ def test_two_ranks_as_typed(gpu):
     assert d["config"]["dot_allreduce"] in ("in_kernel_peer_mapped", "host_staged_gloo")
     assert d["config"]["dot_allreduce_reason"] and d["config"]["halo_exchange_reason"]  # which data plane ran, and why
     check_fractions(d)
-    # self-validating: both pre-flight problems, on every data plane that was timed, against closed forms + golden + each other
+    # self-validating: the bench bricks, on every data plane and with every SpMV kernel that was timed, against closed forms + golden + each other
     pf = d["preflight"]
-    assert pf["ok"] and all(c["ok"] for c in pf["checks"]) and len(pf["checks"]) in (1, 2)
+    assert pf["ok"] and all(c["ok"] for c in pf["checks"]) and 1 <= len(pf["checks"]) <= 4
+    assert 0 in [c["spmv_kernel_mode"] for c in pf["checks"]]  # the loop `value` is quoted on was validated
     for c in pf["checks"]:
         assert c["rr0"] == c["rr0_closed_form"] and c["pAp1"] == c["pAp1_closed_form"] and len(set(c["history_sha256_by_rank"])) == 1
         assert c["golden"] == "hpcg32_x2_scs_C64_sigma256" and c["golden_values_compared"] >= 36  # bit for bit vs the oracle's 2-rank run
+    # `value` is the loop whose SpMV streams the reference's arrays; the compressed-mirror loop has a block of its own
+    assert d["ok"] is True and d["config"]["spmv_kernel"] == "spmv_scs64" and d["roofline"]["kernel"] == "spmv_scs64"
+    assert d["config"]["p_update_inside_spmv"] is False and 0 < d["cg_frac_of_roofline"] <= 1.0
+    se = d.get("structure_exploiting")
     # self-diagnosing: per-rank step times, per-kernel breakdown, K < 100 => median of repeats, the second data plane
     assert d["timed_repeats"] == 9 and len(d["ms_per_step_repeats"]) == 9
     pr = d["per_rank"]
     assert len(pr["ms_per_step"]) == 2 and pr["ms_per_step_min"] <= pr["ms_per_step_max"] <= d["ms_per_step"] * 1.0001
     assert len(pr["device"]) == 2 and len(pr["phases_us"]) == 2
-    # (32^3 per rank: the p update rides inside the SpMV launch only where every chunk is a row program, otherwise it is a phase)
-    names = ("spmv", "alpha_step", "r_update", "beta_step", "halo") + (() if d["config"]["p_update_inside_spmv"] else ("p_update",))
-    for name in names:
+    for name in ("spmv", "alpha_step", "r_update", "beta_step", "halo", "p_update"):
         assert d["phases_us"][name] > 0 and d["phases_us_max_over_ranks"][name] >= d["phases_us"][name] * 0.999, name
+    if se:
+        assert se["value"] > 0 and se["spmv_kernel_mode"] >= 3 and len(se["per_rank_ms_per_step"]) == 2 and se["algorithmic_speedup"] > 1
+        assert ("p_update" in se["phases_us"]) != se["p_update_inside_spmv"]
     if d["config"]["dot_allreduce"] == "in_kernel_peer_mapped":
         ro = d["rccl_only"]
         assert ro["value"] > 0 and ro["dot_allreduce"] == "host_staged_gloo" and len(ro["per_rank_ms_per_step"]) == 2
         # without the peer-mapped paths: pack kernel + the local reduce of each dot in front of its all-reduce (the steps themselves
         # ride in the r / p updates), and three communicator calls per body
         assert ro["launches_per_iteration"] == 6 and ro["collective_calls_per_iteration"] == 3 and ro["phases_us"]["alpha_step"] > 0
-        fp = 1 if d["config"]["p_update_inside_spmv"] else 0
-        assert d["config"]["launches_per_iteration"] == 6 - fp and d["config"]["collective_calls_per_iteration"] == 0
-        pi = d["push_inside"]  # third leg: the push inside the SpMV launch, validated by its own pre-flight
-        assert pi["value"] > 0 and pi["launches_per_iteration"] == 5 - fp and pi["preflight"]["ok"]
+        assert d["config"]["collective_calls_per_iteration"] == 0 and 5 <= d["config"]["launches_per_iteration"] <= 7
+        if se:
+            fp = 1 if se["p_update_inside_spmv"] else 0
+            assert se["launches_per_iteration"] == 6 - fp and se["collective_calls_per_iteration"] == 0
+            assert ro["structure_exploiting"]["value"] > 0
+            pi = se["push_inside"]  # third leg: the push inside the SpMV launch, validated by its own pre-flight
+            assert pi["value"] > 0 and pi["launches_per_iteration"] == 5 - fp and pi["preflight"]["ok"]
     else:
         assert "note" in d["rccl_only"]
 
@@ -109,8 +118,10 @@ def test_a_peer_mapped_plane_that_delivers_wrong_values_degrades_to_the_validate
     dg = d["degraded"]
     assert "peer-mapped data plane failed its pre-flight" in dg["why"] and dg["problems"] and "DEGRADED" in err
     pf = d["preflight"]
-    assert pf["ok"] is False and pf["ok_on_the_plane_value_is_quoted_on"] is True
-    assert [c["ok"] for c in pf["checks"]] == [True, False]  # communicator's plane, then the peer-mapped one
+    assert pf["ok"] is False and pf["ok_on_the_plane_value_is_quoted_on"] is True and d["ok"] is False
+    oks = [(c["case"].split(":")[0], c["ok"]) for c in pf["checks"]]  # communicator's plane (every kernel), then the peer-mapped one
+    assert all(ok for pl, ok in oks if pl.startswith("host_staged")) and not any(ok for pl, ok in oks if pl.startswith("peer-mapped"))
+    assert oks[0][0].startswith("host_staged") and oks[-1][0].startswith("peer-mapped")
     # (the rate is the communicator plane's: what the healthy run reports as rccl_only, within rehearsal noise)
     assert 0.3 < d["value"] / ok["rccl_only"]["value"] < 3.0
 
@@ -126,7 +137,9 @@ def test_a_communicator_plane_that_delivers_wrong_values_leaves_the_peer_mapped_
     assert d["value"] > 0 and d["rccl_only"]["value"] is None and d["rccl_only"]["preflight"]["problems"]
     assert d["degraded"]["value_is_quoted_on"] == "peer-mapped data plane" and "PRE-FLIGHT FAILED on the communicator's data plane" in err
     pf = d["preflight"]
-    assert pf["ok"] is False and pf["ok_on_the_plane_value_is_quoted_on"] is True and [c["ok"] for c in pf["checks"]] == [False, True]
+    assert pf["ok"] is False and pf["ok_on_the_plane_value_is_quoted_on"] is True and d["ok"] is False
+    oks = [(c["case"].split(":")[0], c["ok"]) for c in pf["checks"]]
+    assert not any(ok for pl, ok in oks if pl.startswith("host_staged")) and all(ok for pl, ok in oks if pl.startswith("peer-mapped"))
 
 
 def test_a_crash_in_the_peer_mapped_legs_still_yields_the_validated_line(gpu):
@@ -136,6 +149,7 @@ def test_a_crash_in_the_peer_mapped_legs_still_yields_the_validated_line(gpu):
         pytest.skip("one data plane only on this box (no checkpoint): %s" % d["config"].get("dot_allreduce_reason"))
     assert d["value"] > 0 and d["preflight"]["ok"] and d["config"]["data_plane"] == "host_staged_gloo data plane"
     assert "rank 1 exited with code 9" in d["degraded"]["why"] and d["degraded"]["exit_codes"]["1"] == 9
+    assert d["ok"] is False and os.path.exists(d["degraded"]["stderr_files"]["1"])
 
 
 def test_a_rank_whose_wait_runs_out_takes_the_others_with_it_at_once(gpu):
@@ -185,7 +199,7 @@ def test_five_ranks_next_to_the_test_process(gpu):
     d, _ = run_bench("--gpus", "5", "--transport", "host", "--steps", "6", "--warmup", "2", "--n", "32", "--no-cpu")
     assert d["n_gpus"] == 5 and d["value"] > 0 and d["preflight"]["ok"]
     assert all(c["golden"] == "hpcg32_x5_scs_C64_sigma256" for c in d["preflight"]["checks"])
-    assert len(d["per_rank"]["ms_per_step"]) == 5 and len(d["config"]["spmv_kernel_mode_by_rank"]) == 5
+    assert len(d["per_rank"]["ms_per_step"]) == 5 and len(d["config"]["spmv_kernel_mode_structure_exploiting_by_rank"]) == 5
 
 
 @pytest.mark.parametrize("n_ranks,p2p", [(4, "1"), (4, "0"), (3, "1")])
@@ -193,7 +207,7 @@ def test_more_ranks_and_both_data_planes(gpu, n_ranks, p2p):
     d, _ = run_bench("--gpus", str(n_ranks), "--transport", "host", "--steps", "10", "--n", "16", "--no-cpu",
                      env={"SB_P2P": p2p, "SB_P2P_HALO": p2p})
     assert d["n_gpus"] == n_ranks and d["value"] > 0
-    assert len(d["config"]["spmv_kernel_mode_by_rank"]) == n_ranks  # which SpMV kernel every rank's brick got
+    assert len(d["config"]["spmv_kernel_mode_structure_exploiting_by_rank"]) == n_ranks  # which mirror kernel every rank's brick got
     assert d["preflight"]["ok"]
     if p2p == "0":
         assert d["config"]["dot_allreduce"] == "host_staged_gloo" and "SB_P2P=0" in d["config"]["dot_allreduce_reason"]
@@ -206,22 +220,29 @@ def test_single_gpu_line_has_the_contract_keys(gpu):
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None and d["config"]["workload"].startswith("hpcg_27pt_48^3")
+    # `value` / `roofline` are the loop whose SpMV streams the reference's arrays, on SURVEY 8d's algorithmic bytes
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["launches_timed"] == 40 and r["bytes_per_launch"] <= r["algorithmic_bytes_per_launch"] * 1.02
-    assert abs(d["algorithmic_speedup"] - r["algorithmic_bytes_per_launch"] / r["bytes_per_launch"]) < 1e-9
-    if r["kernel"] != "spmv_scs64":
-        rl = d["roofline_reference_layout"]
-        # (where the default launch also takes the p update its algorithmic bytes are the SpMV's + 40 B/row)
-        extra = 40.0 * d["config"]["rows_per_gpu"] if d["config"]["p_update_inside_spmv"] else 0.0
-        assert rl["kernel"] == "spmv_scs64" and rl["bytes_per_launch"] == r["algorithmic_bytes_per_launch"] - extra
-        # the section-8d-valid path has a CLEAN rate of its own in the line, slower than the structure-exploiting default
-        assert 0 < rl["cg_iterations_per_s"] < d["value"] and rl["cg_iterations_per_s"] >= rl["cg_iterations_per_s_with_events"] * 0.9
-        assert rl["phases_us"]["spmv"] > d["phases_us"]["spmv"] and "p_update" in rl["phases_us"]  # (that loop keeps its separate p update)
+    assert r["kernel"] == "spmv_scs64" and d["config"]["spmv_kernel"] == "spmv_scs64" and d["ok"] is True
+    nr = 48 ** 3
+    assert r["launches_timed"] == 40 and r["bytes_per_launch"] == r["algorithmic_bytes_per_launch"]
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
+    # section 8d: bytes of the reference's unfused op list per iteration / ms_per_step stays under the peak
+    oplist = d["cg_reference_oplist_bytes_per_iteration"]
+    assert oplist == 96.0 * nr + r["algorithmic_bytes_per_launch"]
+    assert abs(d["cg_frac_of_roofline"] - d["value"] * oplist / 8e12) < 1e-9 and 0 < d["cg_frac_of_roofline"] <= 1.0
+    assert d["phases_us"]["spmv"] > 0 and "p_update" in d["phases_us"]  # (that loop keeps its separate p update)
+    se = d["structure_exploiting"]  # the compressed-mirror loop, whole, in a block of its own: faster, and not a roofline figure
+    assert se["kernel"] in ("spmv_prog_fusep", "spmv_scs64_pat_masked") and se["value"] > d["value"] and se["algorithmic_speedup"] > 1.0
+    assert se["moved_bytes_per_launch"] < se["algorithmic_bytes_per_launch"] and se["phases_us"]["spmv"] < d["phases_us"]["spmv"]
+    rm = se["roofline_on_moved_bytes"]
+    assert "frac" not in rm and 0 < rm["frac_of_hbm_peak_on_moved_bytes"] <= 1.0 and rm["bytes_per_launch"] == se["moved_bytes_per_launch"]
+    assert se["sustained"]["value"] > 0 and list(d["cg_iterations_per_s_by_spmv_kernel"].values()) == [d["value"], se["value"]]
     # (the breakdown is taken with an event after every launch, ~2-3 us each: its sum brackets the clean step time from above)
     assert d["preflight"]["ok"] and d["timed_repeats"] == 9 and 1e3 * d["ms_per_step"] <= sum(d["phases_us"].values()) <= 3e3 * d["ms_per_step"]
+    assert sorted(c["spmv_kernel_mode"] for c in d["preflight"]["checks"] if "bench bricks" in c["case"]) == [0, se["spmv_kernel_mode"]]
     # informational: the same clean loop over thousands of steps in one go (a K-step window is a short burst between host-side pauses)
-    assert d["sustained"]["steps"] == 4800 and d["sustained"]["value"] > 0.8 * d["value"] and d["sustained"]["reference_layout_value"] > 0
+    assert d["sustained"]["steps"] == 4800 and d["sustained"]["value"] > 0.8 * d["value"]
     cb = d["cpu_baseline"]
     assert cb and cb["value"] > 0 and cb["cores"] >= 1 and cb["nproc"] >= cb["cores"] and cb["kind"] in ("reference", "port")
     check_fractions(d)

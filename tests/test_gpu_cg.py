@@ -373,3 +373,36 @@ def test_multi_rank_kernel_sequence_through_rccl_on_one_gpu(gpu, monkeypatch):
     assert np.array_equal(r["x"], base["x"]) and r["k"] == base["k"]
     o = po.cg(po.GMatrix.generate(16, 16, 16), itermax=40, dot="tree")
     assert np.array_equal(u["rr"], o["rr"])
+
+
+@pytest.mark.parametrize("first,second", [(0, 5), (5, 0)])
+def test_a_kernel_mode_change_between_pieces_of_one_solve_cannot_mix_the_two_p_paths(gpu, first, second):
+    """the p-update plan (inside the SpMV launch with p double-buffered, or in place) is latched by sb_cg_start.  If
+    sb_matrix_use_packed / sb_cg_set_fuse_p is called between two sb_cg_run_iters pieces, the solve keeps the plan it started
+    with -- 3 in-place bodies followed by a fused one used to read the zeroed second p buffer -- and the change applies from the
+    next sb_cg_start.  History and x equal the undisturbed solve, bit for bit."""
+    n, iters = 32, 14
+    p = hostapi.Problem("generate", n, n, n, fmt="scs", Cc=64, sigma=256)
+    if p.use_packed(5) != 5:
+        p.free()
+        pytest.skip("no row programs for this matrix")
+    assert p.use_packed(first) == first
+    ref = hostapi.CG(p)
+    plan = ref.fuse_p()
+    ref.solve(iters, 0.0)
+    rr0, pap0 = ref.history()
+    x0 = ref.solution()
+    ref.free()
+    cg = hostapi.CG(p)
+    cg.start(iters, 0.0)
+    cg.run_iters(3)
+    assert p.use_packed(second) == second  # mid-solve: kernel mode of the matrix changes ...
+    cg.L.sb_cg_set_fuse_p(cg.ptr, 1 if second else 0)  # ... and so does the wish
+    assert cg.fuse_p() == plan             # ... the running solve keeps its plan
+    cg.run_iters(4)
+    assert p.use_packed(first) == first
+    cg.run_iters(iters)
+    cg.finish()
+    rr, pap = cg.history()
+    assert np.array_equal(rr, rr0) and np.array_equal(pap, pap0) and np.array_equal(cg.solution(), x0)
+    cg.free(), p.free()

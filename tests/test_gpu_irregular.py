@@ -113,3 +113,14 @@ def test_full_size_properties(gpu):
     assert np.array_equal(hist[keys[0]][0], o["rr"]) and np.array_equal(hist[keys[0]][1], o["pAp"])
     rr = hist[keys[0]][0]
     assert np.all(np.diff(np.log(rr)) < 0.5) and rr[-1] < 1e-3 * rr[0]  # converging (1.5e6 -> ~30 in 30 iterations)
+    # the REFERENCE ITSELF at this size -- its own reader, convertMatrix and solveCG on the stand-in exported as
+    # a 94 M-entry .mtx (tests/golden/make_golden_irregular_ref.py, build container; the oracle's sequential-dot run equals it bit
+    # for bit, tests/test_oracle_pinning.py).  The GPU's history is within north_star's 1e-12 of it (observed 8.8e-13 / 9.7e-13: the
+    # reference's sequential sum over 1.5 M elements is that far from a CG with exactly rounded dots, the GPU's order 3.4e-15).
+    import json
+    e = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cg_hist_irregular_ref.json")))["irregular80"]
+    assert e["rows"] == g.nr and e["nnz"] == g.nnzTrue
+    ref_rr, ref_pap = np.array([float(v) for v in e["rr"]]), np.array([float(v) for v in e["pAp"]])
+    pap = hist[keys[0]][1]
+    assert (np.abs(rr - ref_rr[:len(rr)]) / ref_rr[:len(rr)]).max() <= 1e-12
+    assert (np.abs(pap - ref_pap[:len(pap)]) / ref_pap[:len(pap)]).max() <= 1e-12

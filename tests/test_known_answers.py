@@ -76,7 +76,7 @@ def test_tree_goldens_start_with_the_closed_forms_and_match_a_fresh_oracle_run()
 
 
 def test_the_benchs_preflight_gate_accepts_the_golden_and_rejects_a_wrong_halo_value():
-    import bench
+    from sparsebench_amd.bench import preflight as bench
     gold = _goldens()
     key = bench.golden_key(32, 4, "scs", 64, 256)
     g = gold[key]
@@ -100,7 +100,7 @@ def test_the_benchs_preflight_gate_accepts_the_golden_and_rejects_a_wrong_halo_v
 
 
 def test_pmc_traffic_is_keyed_on_the_kernel_source_hash(tmp_path, monkeypatch):
-    import bench
+    from sparsebench_amd.bench import line as bench
     h = srchash.csrc_hash()
     assert len(h) == 16 and h == srchash.csrc_hash()
     prof = tmp_path / "profiles"
