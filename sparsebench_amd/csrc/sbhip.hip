@@ -332,10 +332,10 @@ struct sb_cg {
 // its linkage; the helpers in between stay C++.
 
 #ifdef SB_LAB
-const char* sb_version(void) { return "sparsebench_amd sbhip 0.4 (gfx950, LAB build)"; }
+const char* sb_version(void) { return "sparsebench_amd sbhip 0.5 (gfx950, LAB build)"; }
 int sb_lab_build(void) { return 1; }
 #else
-const char* sb_version(void) { return "sparsebench_amd sbhip 0.4 (gfx950)"; }
+const char* sb_version(void) { return "sparsebench_amd sbhip 0.5 (gfx950)"; }
 int sb_lab_build(void) { return 0; }
 #endif
 

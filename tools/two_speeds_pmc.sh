@@ -28,7 +28,9 @@ import re,sys
 v=[float(re.search(r'best segment ([0-9.]+)', l).group(1)) for l in open('$out/scout.txt') if 'best segment' in l]
 print('%.3f' % (max(v)/min(v)-1.0))")
   echo "scout: spread of the plain step times on this box: $spread"
-  if python3 -c "import sys; sys.exit(0 if $spread > 0.04 else 1)"; then rounds=2; else echo "one kind only on this box: no counter rounds"; exit 0; fi
+  if python3 -c "import sys; sys.exit(0 if $spread > 0.04 else 1)"; then rounds=3; else echo "one kind only on this box: no counter rounds"; exit 0; fi
+  # both kinds on this box: is it where the buffers land?  (one process, allocation sequence varied)
+  for j in 1 2 3; do python3 tools/two_speeds_inproc.py 2>> $out/plain.err | grep two_speeds_inproc | tee -a $out/inproc.txt; echo "-- next process" | tee -a $out/inproc.txt; done
 fi
 i=0
 for r in $(seq 1 $rounds); do
