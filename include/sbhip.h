@@ -89,6 +89,17 @@ sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma,
                          const uint32_t* chunkLens, const uint32_t* colInd, const double* val,
                          const uint32_t* oldToNewPerm, const uint32_t* newToOldPerm);
 void sb_matrix_free(sb_matrix* m);
+/* Where the reference-layout stream (val, colInd: what spMVM of src/matrix-SCS.c:198-228 / src/matrix-CRS.c:46-65 reads) sits
+ * in device memory: one slab, the two arrays at the given offsets (0..256 MB each) inside their regions of it.  The same kernel
+ * streams the same bytes 10-20 % faster or slower depending on WHICH memory that is; sb_scs_upload / sb_crs_upload
+ * pick it by measurement, together with the memory of the CG loop's vectors (SB_PLACE=0: everything stays where hipMalloc put
+ * it).  The three calls below are lab calls for uploads made with SB_PLACE=0 (tools/placement_lab*.py). */
+void sb_matrix_place(sb_matrix* m, int colOffMB, int valOffMB);
+void sb_matrix_place_fresh(sb_matrix* m); /* the same arrays in a NEW slab; earlier slabs stay allocated until the commit */
+void sb_matrix_place_commit(sb_matrix* m);
+void sb_matrix_placement(const sb_matrix* m, int out[2]); /* {-1, -1}: not placed */
+int sb_matrix_placement_report(const sb_matrix* m, float us[3]); /* probes the upload's tuner timed; us of a proxy loop body: first arena + hipMalloc's placement, the pair kept, the slowest */
+void sb_matrix_debug_ptrs(const sb_matrix* m, unsigned long long out[4]); /* lab: device addresses of colInd, val, chunkPtr | rowPtr, chunkLens */
 uint32_t sb_matrix_nr(const sb_matrix* m);
 uint32_t sb_matrix_nc(const sb_matrix* m);
 int sb_matrix_is_permuted(const sb_matrix* m); /* 1 for SCS with a non-identity row sort */
@@ -259,6 +270,7 @@ void sb_halo_exchange(sb_halo* h, double* x);
 sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host,
                     const double* xexact_host);
 void sb_cg_free(sb_cg* s);
+void sb_cg_debug_ptrs(const sb_cg* s, unsigned long long out[8]); /* lab: device addresses of r, p, p', Ap, x, b, partials, control block */
 /* fused = 0: the reference's op list (waxpby, spMVM, ddot as separate launches); 1 (default): dots fused into the
  * SpMV / update kernels (5 launches per loop body); 2: additionally the vector phase of a body
  * (alpha | x, r update + r.r | beta, loop test | p update; src/CGSolver.c:124-128 and :107-116) as ONE launch

@@ -235,7 +235,10 @@ def run(ctx, cpu):
                        "p_update_inside_spmv": bool(d["fuse_p"]),
                        "spmv_kernel_mode_structure_exploiting_by_rank": [r["spmv_mode_structure_exploiting"] for r in per_rank],
                        "device_by_rank": [r["device"] for r in per_rank],
-                       "hip_graph": bool(a.graph), "library": ctx.version},
+                       "hip_graph": bool(a.graph), "library": ctx.version,
+                       # which device memory the streamed arrays and the loop's vectors sit in is chosen by measurement at upload
+                       # (DESIGN 4.1): what that tuner saw on this rank
+                       "placement": prob.placement_report()},
             "timed_repeats": ctx.repeats,
             "ms_per_step_repeats": [1e3 * t / K for t in d["t_repeats"]],
             "global_iterations_per_s": it_s,

@@ -13,6 +13,7 @@ def measure(ctx, prob, modes, clean_all=True, phases=True, sustained=False):
     """modes: SpMV kernel modes (sb_matrix_use_packed) to time; the first is the one `value` is quoted on.  Every mode gets a clean
     pass when clean_all (else only the first).  Returns {mode: record}."""
     a, L, K, W = ctx.args, ctx.L, ctx.K, ctx.W
+    prob.use_packed(modes[0])
     cg = ctx.new_cg(prob)
 
     def timed_pass(with_spmv_events, with_phases=False, steps=None):

@@ -35,6 +35,7 @@ SYMBOLS = [
     "sb_cg_set_fuse_p", "sb_cg_fuse_p", "sb_cg_set_fuse_alpha", "sb_cg_set_fuse_beta",
     "sb_malloc_host_visible", "sb_host_visible_reason", "sb_malloc_pinned_host", "sb_free_pinned_host", "sb_copy_counters",
     "sb_region_begin", "sb_region_end", "sb_region_seconds", "sb_region_reset",
+    "sb_matrix_place", "sb_matrix_place_fresh", "sb_matrix_place_commit", "sb_matrix_placement", "sb_matrix_placement_report", "sb_matrix_debug_ptrs", "sb_cg_debug_ptrs",
 ]
 
 _lib = None
@@ -160,6 +161,13 @@ def load():
         "sb_region_end": (None, [C.c_int]),
         "sb_region_seconds": (C.c_double, [C.c_int, C.POINTER(C.c_uint64)]),
         "sb_region_reset": (None, []),
+        "sb_matrix_place": (None, [vp, C.c_int, C.c_int]),
+        "sb_matrix_place_commit": (None, [vp]),
+        "sb_matrix_place_fresh": (None, [vp]),
+        "sb_matrix_placement": (None, [vp, C.POINTER(C.c_int)]),
+        "sb_matrix_debug_ptrs": (None, [vp, C.POINTER(C.c_uint64)]),
+        "sb_matrix_placement_report": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "sb_cg_debug_ptrs": (None, [vp, C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -201,6 +201,18 @@ struct sb_matrix {
   // both
   uint32_t* colInd = nullptr;
   double* val = nullptr;
+  // placement (sb_matrix_place): the reference-layout stream inside ONE slab at chosen offsets; colInd / val then point into it
+  char* slab         = nullptr;
+  size_t slabBytes   = 0;
+  uint32_t* colInd0  = nullptr; // the arrays as first uploaded (source of every re-placement; freed once the placement is final)
+  double* val0       = nullptr;
+  int placeColMB = -1, placeValMB = -1;
+  std::vector<char*> oldSlabs; // sb_matrix_place_fresh: earlier slabs, kept allocated until the placement is final
+  float placeUs[3] = { 0.f, 0.f, 0.f }; // the tuner's proxy-step times: first arena + hipMalloc's own placement, the pair kept, the slowest seen
+  int placeTried = 0;                   // probes the tuner timed (0: it did not run)
+  char* vecArena = nullptr;             // the allocation the tuner found best for the loop's vectors: the next sb_cg_create uses it
+  size_t vecArenaBytes = 0;
+  bool vecArenaBusy = false;
   // SCS C=64: device-private compressed mirror (pack.hip.h)
   PackMeta* pmeta = nullptr;
   uint32_t *pidx = nullptr, *pcodes = nullptr;
@@ -281,6 +293,9 @@ struct sb_cg {
   // p double-buffered for the SpMV that takes the p update (pack.hip.h: spmv_prog_fusep): body k reads pbuf[(k-1) & 1] and
   // writes pbuf[k & 1]; pbuf[0] == p
   double* pbuf[2] = { nullptr, nullptr };
+  char* vecSlab = nullptr; // the loop's vectors live in ONE allocation, `vecPad` bytes apart (sb_cg_create)
+  size_t vecPad = 0, vecSlabBytes = 0;
+  bool vecFromArena = false; // the vectors sit in the matrix's tuned arena (sb_matrix::vecArena), not in an allocation of their own
   int fusepPlan = -1; // 1: the loop uses spmv_prog_fusep, 0: not, -1: not decided yet
   int fusepWant = -1; // sb_cg_set_fuse_p: 1 / 0, -1: SB_FUSE_P or the library default
   int fusepLatched = -1; // the plan of the solve that is running (set by sb_cg_start, cleared by sb_cg_finish)

@@ -45,6 +45,23 @@ static void phase_mark(sb_cg* s, int ph)
   s->phUsed++;
 }
 
+// ---- where the loop's vectors live ------------------------------------------------------------------------------------------
+// r, Ap, x, b, p, p' (and xexact) sit in ONE allocation, laid out by vec_layout (sbhip_launch.inc.h).  Which memory that is moves
+// the CG step of the section-8d loop by up to 10 %: the upload's placement tuner has measured a good one together with the
+// matrix's own placement (sb_matrix::vecArena) and the first sb_cg of a matrix takes it; a second sb_cg on the same matrix while
+// the first is alive allocates its own.
+static void cg_point_vectors(sb_cg* s, char* slab, bool hasExact)
+{
+  const VecLayout L = vec_layout(s->nr, s->nc, hasExact, s->vecPad);
+  auto at = [&](size_t o) { return reinterpret_cast<double*>(slab + o); };
+  s->vecSlab = slab;
+  s->r = at(L.r), s->Ap = at(L.Ap), s->x = at(L.x), s->b = at(L.b);
+  s->p = at(L.p); // nc = nr + externals (src/CGSolver.c:70)
+  s->pbuf[0] = s->p;
+  s->pbuf[1] = at(L.p2); // second p of the fused p update (fusep_plan)
+  s->xexact  = hasExact ? at(L.xexact) : nullptr;
+}
+
 sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host, const double* xexact_host)
 {
   need_init();
@@ -53,14 +70,18 @@ sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host, con
   if (halo && halo->nr != m->nr) SB_FATAL("halo plan and matrix disagree on nr");
   if (halo && m->nr + (uint32_t)halo->externalCount != m->nc) SB_FATAL("halo externalCount != nc-nr");
   const size_t nb = (size_t)m->nr * sizeof(double);
-  s->r  = (double*)sb_malloc(nb);
-  s->Ap = (double*)sb_malloc(nb);
-  s->x  = (double*)sb_malloc(nb);
-  s->b  = (double*)sb_malloc(nb);
-  s->p  = (double*)sb_malloc((size_t)m->nc * sizeof(double)); // nc = nr + externals (src/CGSolver.c:70)
-  s->pbuf[0] = s->p;
-  s->pbuf[1] = (double*)sb_malloc((size_t)m->nc * sizeof(double)); // second p of the fused p update (fusep_plan)
-  s->xexact = xexact_host ? (double*)sb_malloc(nb) : nullptr;
+  // r, Ap, x, b, p, p' (and xexact) in ONE allocation: the matrix's tuned arena if it is free, else an allocation of their own
+  s->vecPad       = getenv("SB_CG_VEC_PAD_KB") ? (size_t)atol(getenv("SB_CG_VEC_PAD_KB")) << 10 : 0;
+  s->vecSlabBytes = vec_layout(s->nr, s->nc, xexact_host != nullptr, s->vecPad).total;
+  {
+    sb_matrix* A = const_cast<sb_matrix*>(m);
+    if (A->vecArena && !A->vecArenaBusy && s->vecPad == 0 && s->vecSlabBytes <= A->vecArenaBytes) {
+      A->vecArenaBusy = true, s->vecFromArena = true;
+      cg_point_vectors(s, A->vecArena, xexact_host != nullptr);
+    } else {
+      cg_point_vectors(s, (char*)sb_malloc(s->vecSlabBytes), xexact_host != nullptr);
+    }
+  }
   double* tmp = scratch_ws(0, m->nr);
   sb_h2d(tmp, b_host, nb);
   sb_permute(m, tmp, s->b);
@@ -103,6 +124,13 @@ sb_cg* sb_cg_create(const sb_matrix* m, sb_halo* halo, const double* b_host, con
   return s;
 }
 
+// (lab: tools/placement_lab2.py) device addresses of the loop's vectors: r, p (both buffers), Ap, x, b, partials
+void sb_cg_debug_ptrs(const sb_cg* s, unsigned long long out[8])
+{
+  const void* v[8] = { s->r, s->pbuf[0], s->pbuf[1], s->Ap, s->x, s->b, s->partials, s->S };
+  for (int i = 0; i < 8; i++) out[i] = (unsigned long long)v[i];
+}
+
 void sb_cg_free(sb_cg* s)
 {
   if (!s) return;
@@ -117,7 +145,8 @@ void sb_cg_free(sb_cg* s)
   for (hipEvent_t e : s->phEv) HIP_CHECK(hipEventDestroy(e));
   HIP_CHECK(hipEventDestroy(s->evLoop0));
   HIP_CHECK(hipEventDestroy(s->evLoop1));
-  sb_free(s->r), sb_free(s->Ap), sb_free(s->x), sb_free(s->b), sb_free(s->pbuf[0]), sb_free(s->pbuf[1]), sb_free(s->xexact); // (s->p is one of the two)
+  if (s->vecFromArena) const_cast<sb_matrix*>(s->A)->vecArenaBusy = false; // r, Ap, x, b, both p buffers, xexact: back to the matrix
+  else sb_free(s->vecSlab);
   sb_free(s->S), sb_free(s->partials), sb_free(s->rr_hist), sb_free(s->pAp_hist), sb_free(s->partials2), sb_free(s->vphase), sb_free(s->lead);
   delete s;
 }

@@ -366,3 +366,150 @@ double sb_ddot(uint32_t n, const double* x, const double* y)
   sb_d2h(&r, g.scalar, sizeof r);
   return r;
 }
+
+// ===========================================================================
+// placement tuner (sbhip_matrix.inc.h: "placement of the reference-layout stream")
+// ===========================================================================
+// WHICH device memory the stream and the loop's vectors sit in decides how fast the section-8d loop runs: the same arrays copied
+// into a series of fresh allocations of one process ran at 128 / 128 / 114 / 115 ... us per SpMV launch at HPCG 128^3, the CG
+// step moves between 142 and 157 us with the allocation the vectors got (identical virtual addresses included), and the two
+// interact (profiles/r04_placement_lab*.txt) -- while the position INSIDE an allocation changes nothing (289 offsets:
+// 126.7-128.7 us).  Nothing a process can see (address, size, alignment) tells the kinds apart, so the upload MEASURES, with a
+// proxy of the loop body on the loop's own vector layout (p = r + 0.5 p | Ap = A p | r = r - 1e-3 Ap: no scalars, no
+// communication), in up to SB_PLACE_ROUNDS (3) rounds: SB_PLACE_VEC_TRIES (8) fresh allocations of the vectors' arena with the
+// stream in the home it has, then the stream copied into SB_PLACE_TRIES (4) fresh slabs with the best arena; everything tried
+// stays allocated until the end (so that the next try lands on other memory); a round that has seen both kinds -- they are ~10 %
+// apart -- and holds a pair of the fast one ends the search.  The fastest pair is kept -- the arena stays with the matrix and
+// the next sb_cg_create takes its vectors from it -- the rest is freed.  40-120 ms per upload and, for a moment, up to ROUNDS x
+// TRIES x the stream's size (bounded by the memory that is free).  SB_PLACE=0 switches it off; streams below 64 MB
+// (cache resident) are left alone.  Same bytes, same kernels, same arithmetic: same bits.
+struct VecLayout {
+  size_t r, Ap, x, b, p, p2, xexact, total;
+};
+static size_t vec_up(size_t v, size_t pad) { return ((v + 4095) & ~(size_t)4095) + pad; }
+static VecLayout vec_layout(uint32_t nr, uint32_t nc, bool hasExact, size_t pad)
+{
+  const size_t nb = (size_t)nr * sizeof(double), nbc = (size_t)nc * sizeof(double);
+  VecLayout L;
+  size_t off = 0;
+  auto take = [&](size_t v) { const size_t o = off; off += vec_up(v, pad); return o; };
+  L.r = take(nb), L.Ap = take(nb), L.x = take(nb), L.b = take(nb), L.p = take(nbc), L.p2 = take(nbc);
+  L.xexact = hasExact ? take(nb) : 0;
+  L.total  = off + 4096;
+  return L;
+}
+// one proxy step on vectors at `arena` (laid out as the loop lays them out), best of two batches of four
+static float placement_probe(sb_matrix* m, char* arena, const VecLayout& L, hipEvent_t ea, hipEvent_t eb)
+{
+  double* r  = reinterpret_cast<double*>(arena + L.r);
+  double* p  = reinterpret_cast<double*>(arena + L.p);
+  double* Ap = reinterpret_cast<double*>(arena + L.Ap);
+  auto body = [&]() {
+    launch_waxpby(m->nr, 1.0, r, 0.5, p, p, nullptr);
+    launch_spmv(m, p, Ap, nullptr, nullptr);
+    launch_waxpby(m->nr, 1.0, r, -1e-3, Ap, r, nullptr);
+  };
+  body(), body();
+  float best = 1e30f;
+  for (int rep = 0; rep < 2; rep++) {
+    HIP_CHECK(hipEventRecord(ea, g.stream));
+    for (int i = 0; i < 4; i++) body();
+    HIP_CHECK(hipEventRecord(eb, g.stream));
+    HIP_CHECK(hipEventSynchronize(eb));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, ea, eb));
+    best = std::min(best, 1e3f * ms / 4.f);
+  }
+  return best;
+}
+static void tune_matrix_placement(sb_matrix* m)
+{
+  const char* off = getenv("SB_PLACE");
+  if ((off && atoi(off) == 0) || !g_tunePlacement) return;
+  if (!m || !m->colInd || !m->val || m->nr == 0) return;
+  if (m->fmt == 1 && m->C != 64) return;
+  const size_t ne = place_elems(m), colBytes = ne * sizeof(uint32_t), valBytes = ne * sizeof(double);
+  if (colBytes + valBytes < ((size_t)64 << 20)) return;
+  const char* te   = getenv("SB_PLACE_TRIES");
+  const int tries  = std::max(0, te ? atoi(te) : 4);
+  const char* ve   = getenv("SB_PLACE_VEC_TRIES");
+  const int vtries = std::max(1, ve ? atoi(ve) : 8);
+  const char* re   = getenv("SB_PLACE_ROUNDS");
+  const int rounds = std::max(1, re ? atoi(re) : 3);
+  const size_t colRegion = ((colBytes + ((size_t)2 << 20) - 1) >> 21) << 21, slabBytes = colRegion + valBytes + ((size_t)2 << 20);
+  const VecLayout L = vec_layout(m->nr, m->nc, true, 0);
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  hipEvent_t ea, eb;
+  HIP_CHECK(hipEventCreate(&ea));
+  HIP_CHECK(hipEventCreate(&eb));
+  const int mode = m->usePacked;
+  m->usePacked   = 0; // the kernel that streams these arrays
+  uint32_t* const col0 = m->colInd;
+  double* const val0   = m->val;
+  std::vector<char*> arenas, slabs; // everything tried stays allocated to the end: the next try lands on OTHER memory
+  char *arena = nullptr, *home = nullptr; // the pair kept so far (home == nullptr: the stream where hipMalloc put it)
+  float tFirst = 0.f, tBest = 1e30f, tWorst = 0.f;
+  int timed = 0;
+  auto room = [&](size_t bytes) { // (never more than the memory that is free, and 2 GiB to spare)
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return bytes + ((size_t)2 << 30) <= freeB;
+  };
+  auto point_stream = [&](char* sl) {
+    m->colInd = sl ? reinterpret_cast<uint32_t*>(sl) : col0, m->val = sl ? reinterpret_cast<double*>(sl + colRegion) : val0;
+  };
+  for (int round = 0; round < rounds; round++) {
+    // the vectors' arena, stream in the home it has now
+    for (int k = 0; k < vtries && room(L.total); k++) {
+      char* q = nullptr;
+      if (hipMalloc(&q, L.total) != hipSuccess) { (void)hipGetLastError(); break; }
+      arenas.push_back(q);
+      HIP_CHECK(hipMemsetAsync(q, 0, L.total, g.stream));
+      // r and p as a right-hand side would fill them (all-zero vectors would let the clock rise): 0x3f3f... = 4.8e-4
+      HIP_CHECK(hipMemsetAsync(q + L.r, 0x3f, (size_t)m->nr * sizeof(double), g.stream));
+      HIP_CHECK(hipMemsetAsync(q + L.p, 0x3f, (size_t)m->nr * sizeof(double), g.stream));
+      const float t = placement_probe(m, q, L, ea, eb);
+      if (timed++ == 0) tFirst = t; // what a process gets without looking: first allocation, stream where hipMalloc put it
+      tWorst = std::max(tWorst, t);
+      if (t < tBest * (arena ? 0.985f : 1.0f)) tBest = t, arena = q; // (a new home has to be worth it: 1.5 %)
+    }
+    if (!arena) break;
+    // the stream in fresh slabs, best arena
+    for (int k = 0; k < tries && room(slabBytes); k++) {
+      char* sl = nullptr;
+      if (hipMalloc(&sl, slabBytes) != hipSuccess) { (void)hipGetLastError(); break; }
+      slabs.push_back(sl);
+      HIP_CHECK(hipMemcpy(sl, col0, colBytes, hipMemcpyDeviceToDevice));
+      HIP_CHECK(hipMemcpy(sl + colRegion, val0, valBytes, hipMemcpyDeviceToDevice));
+      point_stream(sl);
+      const float t = placement_probe(m, arena, L, ea, eb);
+      timed++;
+      tWorst = std::max(tWorst, t);
+      if (t < tBest * 0.985f) tBest = t, home = sl;
+      point_stream(home);
+    }
+    if (tBest <= 0.92f * tWorst) break; // both kinds seen and the pair kept is of the fast one (they are ~10 % apart)
+  }
+  point_stream(home);
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  for (char* q : arenas)
+    if (q != arena) HIP_CHECK(hipFree(q));
+  for (char* sl : slabs)
+    if (sl != home) HIP_CHECK(hipFree(sl));
+  if (home) {
+    m->slab = home, m->slabBytes = slabBytes, m->placeColMB = 0, m->placeValMB = 0;
+    HIP_CHECK(hipFree(col0));
+    HIP_CHECK(hipFree(val0));
+  }
+  m->vecArena = arena, m->vecArenaBytes = arena ? L.total : 0, m->vecArenaBusy = false;
+  m->placeTried = timed;
+  m->placeUs[0] = tFirst, m->placeUs[1] = tBest, m->placeUs[2] = tWorst;
+  m->usePacked  = mode;
+  HIP_CHECK(hipEventDestroy(ea));
+  HIP_CHECK(hipEventDestroy(eb));
+  if (getenv("SB_PLACE_REPORT"))
+    fprintf(stderr, "sbhip placement: stream of %.1f MB + vectors' arena of %.1f MB: proxy step %.2f us with the first arena tried and "
+        "the stream where hipMalloc put it, %.2f us at the pair kept (%s; %d probes, slowest %.2f us)\n",
+        1e-6 * (double)(colBytes + valBytes), 1e-6 * (double)L.total, tFirst, tBest, home ? "stream moved to a fresh slab" : "stream stays",
+        timed, tWorst);
+}

@@ -13,6 +13,9 @@ static void* upload(const void* host, size_t bytes)
 
 static void build_crs_mirror(sb_matrix* m, const uint32_t* rowPtr, const uint32_t* colInd, const double* val);
 
+static void tune_matrix_placement(sb_matrix* m); // (sbhip_launch.inc.h, behind launch_spmv)
+static bool g_tunePlacement = true;               // off while an upload builds a device-private mirror (its reference arrays are freed again)
+
 sb_matrix* sb_crs_upload(uint32_t nr, uint32_t nc, const uint32_t* rowPtr, const uint32_t* colInd,
     const double* val)
 {
@@ -68,6 +71,7 @@ sb_matrix* sb_crs_upload(uint32_t nr, uint32_t nc, const uint32_t* rowPtr, const
     HIP_CHECK(hipMemcpy(m->val, val, (size_t)m->nnz * sizeof(double), hipMemcpyHostToDevice));
   }
   build_crs_mirror(m, rowPtr, colInd, val);
+  tune_matrix_placement(m);
   return m;
 }
 
@@ -1135,6 +1139,7 @@ sb_matrix* sb_scs_upload(uint32_t nr, uint32_t nc, uint32_t C, uint32_t sigma, u
 #ifndef SB_LAB
   product_modes_only(m);
 #endif
+  tune_matrix_placement(m);
   return m;
 }
 
@@ -1184,8 +1189,10 @@ static void build_crs_mirror(sb_matrix* m, const uint32_t* rowPtr, const uint32_
       sval[at + (size_t)(j - rowPtr[i]) * 64] = val[j];
     }
   }
-  sb_matrix* mm = sb_scs_upload(nr, m->nc, 64, 1, nChunks, (uint32_t)total, chunkPtr.data(), chunkLens.data(),
+  g_tunePlacement = false; // (the mirror's Sell-64-1 arrays only feed its pattern levels and are freed below)
+  sb_matrix* mm   = sb_scs_upload(nr, m->nc, 64, 1, nChunks, (uint32_t)total, chunkPtr.data(), chunkLens.data(),
       scol.data(), sval.data(), nullptr, nullptr);
+  g_tunePlacement = true;
 #ifdef SB_LAB
   const bool useless = mm->nPatClasses == 0;
 #else
@@ -1202,9 +1209,89 @@ static void build_crs_mirror(sb_matrix* m, const uint32_t* rowPtr, const uint32_
   m->usePacked = mm->usePacked >= 3 ? mm->usePacked : 0; // the same size rule as for SCS matrices
 }
 
+// ---- placement of the reference-layout stream ----------------------------------------------------------------------------
+// Where val / colInd sit in device memory decides how fast the section-8d kernel streams them (round 4, tools/placement_lab.py,
+// profiles/r04_two_speeds_*: the same kernel on the same box runs at 117 ... 141 us per launch at 128^3 depending on where the
+// process's allocations happened to land; within a process the time follows the offset of the arrays, in steps).  So the arrays
+// live in ONE slab with PLACE_SPAN bytes of play for each, at offsets the caller (or the tuner below) chooses; moving them is a
+// device-to-device copy.  Number of stored elements of the stream: nElems + SCS_SLACK (SCS), nnz + 64 (CRS).
+constexpr size_t PLACE_SPAN = (size_t)256 << 20;
+static size_t place_elems(const sb_matrix* m) { return m->fmt == 1 ? (size_t)m->nElems + SCS_SLACK : (size_t)m->nnz + 64; }
+void sb_matrix_place(sb_matrix* m, int colOffMB, int valOffMB)
+{
+  need_init();
+  if (!m || !m->colInd || !m->val) return;
+  if (m->placeTried) SB_FATAL("sb_matrix_place is a lab call: upload with SB_PLACE=0 (the upload's tuner has placed this matrix)");
+  if (colOffMB < 0 || valOffMB < 0 || (size_t)colOffMB << 20 > PLACE_SPAN || (size_t)valOffMB << 20 > PLACE_SPAN)
+    SB_FATAL("sb_matrix_place: offsets must lie in [0, %zu] MB", PLACE_SPAN >> 20);
+  const size_t ne = place_elems(m), colBytes = ne * sizeof(uint32_t), valBytes = ne * sizeof(double);
+  const size_t colRegion = ((colBytes + PLACE_SPAN + ((size_t)2 << 20) - 1) >> 21) << 21;
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  if (!m->slab) {
+    m->slabBytes = colRegion + valBytes + PLACE_SPAN + ((size_t)2 << 20);
+    HIP_CHECK(hipMalloc(&m->slab, m->slabBytes));
+    m->colInd0 = m->colInd, m->val0 = m->val; // keep the first upload as the source of every placement
+  }
+  uint32_t* c = reinterpret_cast<uint32_t*>(m->slab + ((size_t)colOffMB << 20));
+  double* v   = reinterpret_cast<double*>(m->slab + colRegion + ((size_t)valOffMB << 20));
+  HIP_CHECK(hipMemcpy(c, m->colInd0, colBytes, hipMemcpyDeviceToDevice));
+  HIP_CHECK(hipMemcpy(v, m->val0, valBytes, hipMemcpyDeviceToDevice));
+  m->colInd = c, m->val = v, m->placeColMB = colOffMB, m->placeValMB = valOffMB;
+}
+// the same arrays in a NEW slab (another piece of device memory; the earlier slabs stay allocated, so the new one cannot land on
+// the same pages): what sb_matrix_place cannot vary is WHICH memory the slab is made of
+void sb_matrix_place_fresh(sb_matrix* m)
+{
+  need_init();
+  if (!m || !m->colInd || !m->val) return;
+  if (m->placeTried) SB_FATAL("sb_matrix_place_fresh is a lab call: upload with SB_PLACE=0 (the upload's tuner has placed this matrix)");
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  if (m->slab) m->oldSlabs.push_back(m->slab), m->slab = nullptr;
+  else m->colInd0 = m->colInd, m->val0 = m->val;
+  const size_t ne = place_elems(m), colBytes = ne * sizeof(uint32_t), valBytes = ne * sizeof(double);
+  const size_t colRegion = ((colBytes + PLACE_SPAN + ((size_t)2 << 20) - 1) >> 21) << 21;
+  m->slabBytes = colRegion + valBytes + PLACE_SPAN + ((size_t)2 << 20);
+  HIP_CHECK(hipMalloc(&m->slab, m->slabBytes));
+  uint32_t* c = reinterpret_cast<uint32_t*>(m->slab);
+  double* v   = reinterpret_cast<double*>(m->slab + colRegion);
+  HIP_CHECK(hipMemcpy(c, m->colInd0, colBytes, hipMemcpyDeviceToDevice));
+  HIP_CHECK(hipMemcpy(v, m->val0, valBytes, hipMemcpyDeviceToDevice));
+  m->colInd = c, m->val = v, m->placeColMB = 0, m->placeValMB = 0;
+}
+// the placement is final: the first upload and the slabs tried before go
+void sb_matrix_place_commit(sb_matrix* m)
+{
+  if (!m || !m->slab) return;
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  sb_free(m->colInd0), sb_free(m->val0);
+  m->colInd0 = nullptr, m->val0 = nullptr;
+  for (char* q : m->oldSlabs) sb_free(q);
+  m->oldSlabs.clear();
+}
+void sb_matrix_placement(const sb_matrix* m, int out[2]) { out[0] = m->placeColMB, out[1] = m->placeValMB; }
+// what the placement tuner of the upload saw: probes timed (0: it did not run); us: proxy step of the loop with the first
+// vectors' arena tried and the stream where hipMalloc put it, at the pair that was kept, at the slowest pair seen
+int sb_matrix_placement_report(const sb_matrix* m, float us[3])
+{
+  for (int i = 0; i < 3; i++) us[i] = m->placeUs[i];
+  return m->placeTried;
+}
+// (lab: tools/placement_lab2.py) device addresses of the streamed arrays
+void sb_matrix_debug_ptrs(const sb_matrix* m, unsigned long long out[4])
+{
+  out[0] = (unsigned long long)m->colInd, out[1] = (unsigned long long)m->val;
+  out[2] = (unsigned long long)(m->fmt == 1 ? (void*)m->chunkPtr : (void*)m->rowPtr), out[3] = (unsigned long long)m->chunkLens;
+}
+
 void sb_matrix_free(sb_matrix* m)
 {
   if (!m) return;
+  sb_free(m->vecArena);
+  if (m->slab) { // (colInd / val point into the slab)
+    sb_free(m->slab), sb_free(m->colInd0), sb_free(m->val0);
+    for (char* q : m->oldSlabs) sb_free(q);
+    m->colInd = nullptr, m->val = nullptr;
+  }
   sb_free(m->rowPtr), sb_free(m->rowBlocks), sb_free(m->tileRow), sb_free(m->chunkPtr), sb_free(m->chunkLens);
   sb_free(m->oldToNew), sb_free(m->newToOld), sb_free(m->colInd), sb_free(m->val);
   sb_free(m->pmeta), sb_free(m->pidx), sb_free(m->pcodes), sb_free(m->pdict);

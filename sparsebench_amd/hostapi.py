@@ -169,6 +169,14 @@ class Problem:
         capi.load().sb_matrix_use_packed(self.matrix, int(mode))
         return capi.load().sb_matrix_packed_mode(self.matrix)
 
+    def placement_report(self):
+        """what the upload's placement tuner saw (us of a proxy loop body: p update | SpMV on the reference-layout stream | r update):
+        with the first vectors' arena tried and the stream where hipMalloc put it, at the pair kept, at the slowest pair; None if
+        it did not run (SB_PLACE=0, or a stream below 64 MB)"""
+        us = (C.c_float * 3)()
+        n = capi.load().sb_matrix_placement_report(self.matrix, us)
+        return {"probes_timed": n, "us_first_pair": round(us[0], 2), "us_kept": round(us[1], 2), "us_slowest": round(us[2], 2)} if n else None
+
     def pack_info(self):
         L = capi.load()
         uni = C.c_uint32(0)

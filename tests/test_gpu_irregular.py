@@ -3,6 +3,8 @@ offline; the matrix is the committed stand-in "irregular", host/sbh_irregular.c)
 bit-equal to the oracle (SpMV and 30+ CG iterations).  Full size (80^3 nodes, 1.5 M rows, 94 M nonzeros): SpMV
 bit-equal to the oracle's CRS loop, and the size-independent properties CRS history == Sell-C-1 history,
 <y, A x> == <x, A y> to rounding, fused == unfused."""
+import os
+
 import numpy as np
 import pytest
 

@@ -9,7 +9,7 @@ import pytest
 
 from conftest import REFDATA, lab_build, load_json, modes_scs
 from oracle import pyoracle as po
-from sparsebench_amd import capi
+from sparsebench_amd import capi, hostapi
 from sparsebench_amd.capi import DeviceVector
 
 pytestmark = pytest.mark.gpu
@@ -555,3 +555,32 @@ def test_crs_through_its_pattern_mirror(gpu, monkeypatch):
     ok = ~np.isnan(exp)
     assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(got[ok].view(np.uint64), exp[ok].view(np.uint64))
     L.sb_matrix_free(m)
+
+
+def test_placement_tuner_picks_memory_by_measurement_and_changes_no_bit(gpu, monkeypatch):
+    """Round 4: which device memory the reference-layout stream sits in decides how fast spmv_scs64 reads it (the same
+    arrays in a series of fresh allocations of one process: 128 / 128 / 114 / 115 ... us per launch), so the upload copies the
+    stream into a few fresh slabs, times the kernel on each and keeps the fastest; sb_cg_create does the same for the loop's
+    vectors.  Same bytes, same kernel: the product and the CG history are the bits of the untuned run."""
+    n = 96  # 884 736 rows: a 282 MB stream (tuned)
+    rng = np.random.default_rng(11)
+    outs = {}
+    for place in ("0", "1"):
+        monkeypatch.setenv("SB_PLACE", place)
+        prob = hostapi.Problem("generate", n, n, n, fmt="scs", Cc=64, sigma=256)
+        assert prob.use_packed(0) == 0
+        rep = prob.placement_report()
+        if place == "0":
+            assert rep is None
+        else:
+            assert rep["probes_timed"] >= 3 and rep["us_kept"] <= rep["us_first_pair"] <= rep["us_slowest"] * 1.0001
+        x = rng.standard_normal(prob.nc) if not outs else outs["x"]
+        outs["x"] = x
+        dx, dy = DeviceVector.from_host(x), DeviceVector(prob.nr)
+        gpu.sb_spmv_native(prob.matrix, dx.ptr, dy.ptr)
+        cg = hostapi.CG(prob)
+        cg.solve(12, 0.0)
+        outs[place] = (dy.get().copy(), cg.history())
+        dx.free(), dy.free(), cg.free(), prob.free()
+    assert np.array_equal(outs["0"][0], outs["1"][0])
+    assert np.array_equal(outs["0"][1][0], outs["1"][1][0]) and np.array_equal(outs["0"][1][1], outs["1"][1][1])

@@ -4,9 +4,11 @@ process, several uploads, each behind dummy device allocations of different size
 and the CG vectors) so that matrix and vectors land at other physical / virtual offsets each time; everything is freed in
 between.  Round 3 found all uploads of a process at that process's speed with identical allocation sequences; this varies the
 sequence.  usage: two_speeds_inproc.py"""
+import os
 import sys
 import time
 
+os.environ.setdefault("SB_PLACE", "0")  # (a lab of the placement itself: the upload's tuner stays out of it)
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from sparsebench_amd import capi, hostapi  # noqa: E402
 
