@@ -98,6 +98,10 @@ void sb_matrix_place(sb_matrix* m, int colOffMB, int valOffMB);
 void sb_matrix_place_fresh(sb_matrix* m); /* the same arrays in a NEW slab; earlier slabs stay allocated until the commit */
 void sb_matrix_place_commit(sb_matrix* m);
 void sb_matrix_placement(const sb_matrix* m, int out[2]); /* {-1, -1}: not placed */
+void sb_matrix_place_at(sb_matrix* m, void* colMem, void* valMem); /* lab: the stream copied to the caller's memory */
+void sb_matrix_place_home(sb_matrix* m);                            /* lab: back to the first upload */
+size_t sb_placement_arena_bytes(const sb_matrix* m);                /* lab: bytes of the loop's vector layout */
+float sb_placement_probe(sb_matrix* m, void* arena);                /* lab: the tuner's proxy step (us) with the vectors at `arena` */
 int sb_matrix_placement_report(const sb_matrix* m, float us[3]); /* probes the upload's tuner timed; us of a proxy loop body: first arena + hipMalloc's placement, the pair kept, the slowest */
 void sb_matrix_debug_ptrs(const sb_matrix* m, unsigned long long out[4]); /* lab: device addresses of colInd, val, chunkPtr | rowPtr, chunkLens */
 uint32_t sb_matrix_nr(const sb_matrix* m);

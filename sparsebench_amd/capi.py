@@ -35,7 +35,7 @@ SYMBOLS = [
     "sb_cg_set_fuse_p", "sb_cg_fuse_p", "sb_cg_set_fuse_alpha", "sb_cg_set_fuse_beta",
     "sb_malloc_host_visible", "sb_host_visible_reason", "sb_malloc_pinned_host", "sb_free_pinned_host", "sb_copy_counters",
     "sb_region_begin", "sb_region_end", "sb_region_seconds", "sb_region_reset",
-    "sb_matrix_place", "sb_matrix_place_fresh", "sb_matrix_place_commit", "sb_matrix_placement", "sb_matrix_placement_report", "sb_matrix_debug_ptrs", "sb_cg_debug_ptrs",
+    "sb_matrix_place", "sb_matrix_place_at", "sb_matrix_place_home", "sb_placement_arena_bytes", "sb_placement_probe", "sb_matrix_place_fresh", "sb_matrix_place_commit", "sb_matrix_placement", "sb_matrix_placement_report", "sb_matrix_debug_ptrs", "sb_cg_debug_ptrs",
 ]
 
 _lib = None
@@ -164,6 +164,10 @@ def load():
         "sb_matrix_place": (None, [vp, C.c_int, C.c_int]),
         "sb_matrix_place_commit": (None, [vp]),
         "sb_matrix_place_fresh": (None, [vp]),
+        "sb_matrix_place_at": (None, [vp, vp, vp]),
+        "sb_matrix_place_home": (None, [vp]),
+        "sb_placement_arena_bytes": (C.c_size_t, [vp]),
+        "sb_placement_probe": (C.c_float, [vp, vp]),
         "sb_matrix_placement": (None, [vp, C.POINTER(C.c_int)]),
         "sb_matrix_debug_ptrs": (None, [vp, C.POINTER(C.c_uint64)]),
         "sb_matrix_placement_report": (C.c_int, [vp, C.POINTER(C.c_float)]),

@@ -376,10 +376,16 @@ double sb_ddot(uint32_t n, const double* x, const double* y)
 // interact (profiles/r04_placement_lab*.txt) -- while the position INSIDE an allocation changes nothing (289 offsets:
 // 126.7-128.7 us).  Nothing a process can see (address, size, alignment) tells the kinds apart, so the upload MEASURES, with a
 // proxy of the loop body on the loop's own vector layout (p = r + 0.5 p | Ap = A p | r = r - 1e-3 Ap: no scalars, no
-// communication), in up to SB_PLACE_ROUNDS (3) rounds: SB_PLACE_VEC_TRIES (8) fresh allocations of the vectors' arena with the
+// communication), in up to SB_PLACE_ROUNDS (6) rounds: SB_PLACE_VEC_TRIES (8) fresh allocations of the vectors' arena with the
 // stream in the home it has, then the stream copied into SB_PLACE_TRIES (4) fresh slabs with the best arena; everything tried
-// stays allocated until the end (so that the next try lands on other memory); a round that has seen both kinds -- they are ~10 %
-// apart -- and holds a pair of the fast one ends the search.  The fastest pair is kept -- the arena stays with the matrix and
+// stays allocated until the end (so that the next try lands on other memory), and a round that found nothing better is followed by
+// 8 / 16 GiB of ballast (to jump further away); the search ends once the pair kept is >= 11.5 % faster than the slowest pair seen
+// (fast and slow pairs are 13-15 % apart: pairs come in two kinds, roughly half of each, in long runs along the allocation order
+// -- 131-134 against 153-156 us per proxy step, with the stream fixed as with the arena fixed) or after three rounds in a row without
+// anything better (some devices of the pool have no fast pairs at all: 48 probes between 151 and 156 us).  Physically contiguous allocations (hipDeviceMallocContiguous) and power-of-two sizes (one aligned buddy block per buffer) behave
+// the same, and stream + vectors at 256 position pairs inside ONE 48 GiB allocation are all of the slow kind: it is neither
+// fragmentation nor page-table fragment size, and it needs two allocations (profiles/r04_placement_probe_sequences.txt,
+// r04_placement_lab6.txt).  The mechanism is not understood.  The fastest pair is kept -- the arena stays with the matrix and
 // the next sb_cg_create takes its vectors from it -- the rest is freed.  40-120 ms per upload and, for a moment, up to ROUNDS x
 // TRIES x the stream's size (bounded by the memory that is free).  SB_PLACE=0 switches it off; streams below 64 MB
 // (cache resident) are left alone.  Same bytes, same kernels, same arithmetic: same bits.
@@ -426,6 +432,7 @@ static void tune_matrix_placement(sb_matrix* m)
 {
   const char* off = getenv("SB_PLACE");
   if ((off && atoi(off) == 0) || !g_tunePlacement) return;
+  if (getenv("SB_SHARED_GPU") && atoi(getenv("SB_SHARED_GPU")) != 0) return; // ranks share this GPU (a rehearsal): timings mean nothing, memory is shared
   if (!m || !m->colInd || !m->val || m->nr == 0) return;
   if (m->fmt == 1 && m->C != 64) return;
   const size_t ne = place_elems(m), colBytes = ne * sizeof(uint32_t), valBytes = ne * sizeof(double);
@@ -435,7 +442,8 @@ static void tune_matrix_placement(sb_matrix* m)
   const char* ve   = getenv("SB_PLACE_VEC_TRIES");
   const int vtries = std::max(1, ve ? atoi(ve) : 8);
   const char* re   = getenv("SB_PLACE_ROUNDS");
-  const int rounds = std::max(1, re ? atoi(re) : 3);
+  const int rounds = std::max(1, re ? atoi(re) : 6);
+  const int verbose = getenv("SB_PLACE_REPORT") ? atoi(getenv("SB_PLACE_REPORT")) : 0;
   const size_t colRegion = ((colBytes + ((size_t)2 << 20) - 1) >> 21) << 21, slabBytes = colRegion + valBytes + ((size_t)2 << 20);
   const VecLayout L = vec_layout(m->nr, m->nc, true, 0);
   HIP_CHECK(hipStreamSynchronize(g.stream));
@@ -446,19 +454,25 @@ static void tune_matrix_placement(sb_matrix* m)
   m->usePacked   = 0; // the kernel that streams these arrays
   uint32_t* const col0 = m->colInd;
   double* const val0   = m->val;
-  std::vector<char*> arenas, slabs; // everything tried stays allocated to the end: the next try lands on OTHER memory
+  std::vector<char*> arenas, slabs, ballast; // everything tried stays allocated to the end: the next try lands on OTHER memory
   char *arena = nullptr, *home = nullptr; // the pair kept so far (home == nullptr: the stream where hipMalloc put it)
   float tFirst = 0.f, tBest = 1e30f, tWorst = 0.f;
   int timed = 0;
-  auto room = [&](size_t bytes) { // (never more than the memory that is free, and 2 GiB to spare)
+  size_t held = 0; // bytes the search holds at the moment
+  auto room = [&](size_t bytes) { // (never more than a quarter of the device, nor than what is free with 2 GiB to spare)
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return bytes + ((size_t)2 << 30) <= freeB;
+    if (held + bytes > totalB / 4) return false;
+    if (bytes + ((size_t)2 << 30) > freeB) return false;
+    held += bytes;
+    return true;
   };
   auto point_stream = [&](char* sl) {
     m->colInd = sl ? reinterpret_cast<uint32_t*>(sl) : col0, m->val = sl ? reinterpret_cast<double*>(sl + colRegion) : val0;
   };
+  int idle = 0; // consecutive rounds that found nothing better
   for (int round = 0; round < rounds; round++) {
+    const float tBefore = tBest;
     // the vectors' arena, stream in the home it has now
     for (int k = 0; k < vtries && room(L.total); k++) {
       char* q = nullptr;
@@ -470,6 +484,7 @@ static void tune_matrix_placement(sb_matrix* m)
       HIP_CHECK(hipMemsetAsync(q + L.p, 0x3f, (size_t)m->nr * sizeof(double), g.stream));
       const float t = placement_probe(m, q, L, ea, eb);
       if (timed++ == 0) tFirst = t; // what a process gets without looking: first allocation, stream where hipMalloc put it
+      if (verbose > 1) fprintf(stderr, "sbhip placement: round %d arena %d (%p): %.2f us\n", round, k, (void*)q, t);
       tWorst = std::max(tWorst, t);
       if (t < tBest * (arena ? 0.985f : 1.0f)) tBest = t, arena = q; // (a new home has to be worth it: 1.5 %)
     }
@@ -484,11 +499,20 @@ static void tune_matrix_placement(sb_matrix* m)
       point_stream(sl);
       const float t = placement_probe(m, arena, L, ea, eb);
       timed++;
+      if (verbose > 1) fprintf(stderr, "sbhip placement: round %d slab %d (%p): %.2f us\n", round, k, (void*)sl, t);
       tWorst = std::max(tWorst, t);
       if (t < tBest * 0.985f) tBest = t, home = sl;
       point_stream(home);
     }
-    if (tBest <= 0.92f * tWorst) break; // both kinds seen and the pair kept is of the fast one (they are ~10 % apart)
+    if (tBest <= 0.885f * tWorst) break; // the whole range has been seen (fastest and slowest pairs are 13-15 % apart) and the pair kept is at its fast end
+    idle = (round > 0 && tBest > tBefore * 0.985f) ? idle + 1 : 0;
+    if (idle >= 3) break; // three rounds in a row without anything better: this device has nothing faster to offer
+    if (idle >= 1) { // a round that found nothing better: jump further away before the next (8, 16 GiB)
+      const size_t jump = (size_t)8 << (30 + std::min(idle - 1, 1));
+      char* q = nullptr;
+      if (room(jump + ((size_t)1 << 30)) && hipMalloc(&q, jump) == hipSuccess) ballast.push_back(q);
+      else (void)hipGetLastError();
+    }
   }
   point_stream(home);
   HIP_CHECK(hipStreamSynchronize(g.stream));
@@ -496,6 +520,7 @@ static void tune_matrix_placement(sb_matrix* m)
     if (q != arena) HIP_CHECK(hipFree(q));
   for (char* sl : slabs)
     if (sl != home) HIP_CHECK(hipFree(sl));
+  for (char* q : ballast) HIP_CHECK(hipFree(q));
   if (home) {
     m->slab = home, m->slabBytes = slabBytes, m->placeColMB = 0, m->placeValMB = 0;
     HIP_CHECK(hipFree(col0));
@@ -512,4 +537,43 @@ static void tune_matrix_placement(sb_matrix* m)
         "the stream where hipMalloc put it, %.2f us at the pair kept (%s; %d probes, slowest %.2f us)\n",
         1e-6 * (double)(colBytes + valBytes), 1e-6 * (double)L.total, tFirst, tBest, home ? "stream moved to a fresh slab" : "stream stays",
         timed, tWorst);
+}
+
+// ---- lab calls (tools/placement_lab6.py; uploads made with SB_PLACE=0) --------------------------------------------------------
+// the stream copied to memory the CALLER provides (col: place_elems x 4 bytes, val: x 8 bytes; nothing is freed or owned here)
+void sb_matrix_place_at(sb_matrix* m, void* colMem, void* valMem)
+{
+  need_init();
+  if (m->placeTried) SB_FATAL("sb_matrix_place_at is a lab call: upload with SB_PLACE=0");
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  if (!m->colInd0) m->colInd0 = m->colInd, m->val0 = m->val;
+  const size_t ne = place_elems(m);
+  HIP_CHECK(hipMemcpy(colMem, m->colInd0, ne * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+  HIP_CHECK(hipMemcpy(valMem, m->val0, ne * sizeof(double), hipMemcpyDeviceToDevice));
+  m->colInd = (uint32_t*)colMem, m->val = (double*)valMem;
+}
+// back to the first upload (so that sb_matrix_free finds what it allocated)
+void sb_matrix_place_home(sb_matrix* m)
+{
+  if (m->colInd0) m->colInd = m->colInd0, m->val = m->val0, m->colInd0 = nullptr, m->val0 = nullptr;
+}
+// the tuner's proxy step (us) with the loop's vectors laid out at `arena` (sb_placement_arena_bytes of caller's memory)
+size_t sb_placement_arena_bytes(const sb_matrix* m) { return vec_layout(m->nr, m->nc, true, 0).total; }
+float sb_placement_probe(sb_matrix* m, void* arena)
+{
+  need_init();
+  const VecLayout L = vec_layout(m->nr, m->nc, true, 0);
+  HIP_CHECK(hipMemsetAsync(arena, 0, L.total, g.stream));
+  HIP_CHECK(hipMemsetAsync((char*)arena + L.r, 0x3f, (size_t)m->nr * sizeof(double), g.stream));
+  HIP_CHECK(hipMemsetAsync((char*)arena + L.p, 0x3f, (size_t)m->nr * sizeof(double), g.stream));
+  hipEvent_t ea, eb;
+  HIP_CHECK(hipEventCreate(&ea));
+  HIP_CHECK(hipEventCreate(&eb));
+  const int mode = m->usePacked;
+  m->usePacked   = 0;
+  const float t  = placement_probe(m, (char*)arena, L, ea, eb);
+  m->usePacked   = mode;
+  HIP_CHECK(hipEventDestroy(ea));
+  HIP_CHECK(hipEventDestroy(eb));
+  return t;
 }

@@ -30,6 +30,7 @@ def main():
     rank, size = dist.get_rank(), dist.get_world_size()
     fmt, Cc, sigma, n, itermax = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
     workload = sys.argv[6] if len(sys.argv) > 6 else "generate"  # or "irregular": the configs[4] stand-in, n^3 nodes
+    os.environ.setdefault("SB_SHARED_GPU", "1")  # every rank on the one GPU: no placement search (its timings would be each other's noise)
     L = capi.init(0)  # every rank on the one GPU
     H = hostapi.host()
 
