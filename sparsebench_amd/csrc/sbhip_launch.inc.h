@@ -376,12 +376,13 @@ double sb_ddot(uint32_t n, const double* x, const double* y)
 // interact (profiles/r04_placement_lab*.txt) -- while the position INSIDE an allocation changes nothing (289 offsets:
 // 126.7-128.7 us).  Nothing a process can see (address, size, alignment) tells the kinds apart, so the upload MEASURES, with a
 // proxy of the loop body on the loop's own vector layout (p = r + 0.5 p | Ap = A p | r = r - 1e-3 Ap: no scalars, no
-// communication), in up to SB_PLACE_ROUNDS (6) rounds: SB_PLACE_VEC_TRIES (8) fresh allocations of the vectors' arena with the
+// communication), in up to SB_PLACE_ROUNDS (6) rounds: SB_PLACE_VEC_TRIES (10) fresh allocations of the vectors' arena, each
+// followed by a 700 MB spacer (a pair's speed follows how far apart and where its two allocations lie -- within ~2.5 GB of each
+// other: the slow kind; every pair of 8 stream x 16 arena allocations of a process: profiles/r04_placement_lab7.txt), with the
 // stream in the home it has, then the stream copied into SB_PLACE_TRIES (4) fresh slabs with the best arena; everything tried
-// stays allocated until the end (so that the next try lands on other memory), and a round that found nothing better is followed by
-// 8 / 16 GiB of ballast (to jump further away); the search ends once the pair kept is >= 11.5 % faster than the slowest pair seen
-// (fast and slow pairs are 13-15 % apart: pairs come in two kinds, roughly half of each, in long runs along the allocation order
-// -- 131-134 against 153-156 us per proxy step, with the stream fixed as with the arena fixed) or after three rounds in a row without
+// stays allocated until the end (so that the next try lands further on); the search ends once the pair kept is >= 14.5 % faster than the slowest pair seen
+// (pairs come in levels -- 131 | 137-139 | 143 | 147 | 153-157 us per proxy step at HPCG 128^3 -- in long runs along the allocation
+// order, with the stream fixed as with the arena fixed; pairs whose allocations lie within ~2.5 GB of each other are of the slowest) or after three rounds in a row without
 // anything better (some devices of the pool have no fast pairs at all: 48 probes between 151 and 156 us).  Physically contiguous allocations (hipDeviceMallocContiguous) and power-of-two sizes (one aligned buddy block per buffer) behave
 // the same, and stream + vectors at 256 position pairs inside ONE 48 GiB allocation are all of the slow kind: it is neither
 // fragmentation nor page-table fragment size, and it needs two allocations (profiles/r04_placement_probe_sequences.txt,
@@ -440,7 +441,8 @@ static void tune_matrix_placement(sb_matrix* m)
   const char* te   = getenv("SB_PLACE_TRIES");
   const int tries  = std::max(0, te ? atoi(te) : 4);
   const char* ve   = getenv("SB_PLACE_VEC_TRIES");
-  const int vtries = std::max(1, ve ? atoi(ve) : 8);
+  const int vtries = std::max(1, ve ? atoi(ve) : 10);
+  const size_t spacer = (size_t)(getenv("SB_PLACE_SPACER_MB") ? atol(getenv("SB_PLACE_SPACER_MB")) : 700) << 20;
   const char* re   = getenv("SB_PLACE_ROUNDS");
   const int rounds = std::max(1, re ? atoi(re) : 6);
   const int verbose = getenv("SB_PLACE_REPORT") ? atoi(getenv("SB_PLACE_REPORT")) : 0;
@@ -478,6 +480,11 @@ static void tune_matrix_placement(sb_matrix* m)
       char* q = nullptr;
       if (hipMalloc(&q, L.total) != hipSuccess) { (void)hipGetLastError(); break; }
       arenas.push_back(q);
+      if (spacer && room(spacer)) { // the next arena lands `spacer` further on: a pair's speed follows how far apart its two
+        char* sp = nullptr;         // allocations lie (within ~2.5 GB: the slow kind, profiles/r04_placement_lab7.txt)
+        if (hipMalloc(&sp, spacer) == hipSuccess) ballast.push_back(sp);
+        else (void)hipGetLastError();
+      }
       HIP_CHECK(hipMemsetAsync(q, 0, L.total, g.stream));
       // r and p as a right-hand side would fill them (all-zero vectors would let the clock rise): 0x3f3f... = 4.8e-4
       HIP_CHECK(hipMemsetAsync(q + L.r, 0x3f, (size_t)m->nr * sizeof(double), g.stream));
@@ -504,15 +511,10 @@ static void tune_matrix_placement(sb_matrix* m)
       if (t < tBest * 0.985f) tBest = t, home = sl;
       point_stream(home);
     }
-    if (tBest <= 0.885f * tWorst) break; // the whole range has been seen (fastest and slowest pairs are 13-15 % apart) and the pair kept is at its fast end
+    if (tBest <= 0.855f * tWorst) break; // the whole range has been seen and the pair kept is at its fast end (levels at HPCG 128^3: 131 | 137-139 | 143 | 147 | 153-157 us)
     idle = (round > 0 && tBest > tBefore * 0.985f) ? idle + 1 : 0;
     if (idle >= 3) break; // three rounds in a row without anything better: this device has nothing faster to offer
-    if (idle >= 1) { // a round that found nothing better: jump further away before the next (8, 16 GiB)
-      const size_t jump = (size_t)8 << (30 + std::min(idle - 1, 1));
-      char* q = nullptr;
-      if (room(jump + ((size_t)1 << 30)) && hipMalloc(&q, jump) == hipSuccess) ballast.push_back(q);
-      else (void)hipGetLastError();
-    }
+    if (round >= 1 && tWorst <= 1.06f * tBest) break; // two rounds (28 pairs over ~20 GB) within 6 %: a device without the fast kind (one in three of the pool)
   }
   point_stream(home);
   HIP_CHECK(hipStreamSynchronize(g.stream));
