@@ -93,7 +93,7 @@ void sb_matrix_free(sb_matrix* m);
  * in device memory: one slab, the two arrays at the given offsets (0..256 MB each) inside their regions of it.  The same kernel
  * streams the same bytes 10-20 % faster or slower depending on WHICH memory that is; sb_scs_upload / sb_crs_upload
  * pick it by measurement, together with the memory of the CG loop's vectors (SB_PLACE=0: everything stays where hipMalloc put
- * it).  The three calls below are lab calls for uploads made with SB_PLACE=0 (tools/placement_lab*.py). */
+ * it).  The calls below (down to sb_placement_probe) are lab calls for uploads made with SB_PLACE=0 (tools/placement_lab*.py). */
 void sb_matrix_place(sb_matrix* m, int colOffMB, int valOffMB);
 void sb_matrix_place_fresh(sb_matrix* m); /* the same arrays in a NEW slab; earlier slabs stay allocated until the commit */
 void sb_matrix_place_commit(sb_matrix* m);
