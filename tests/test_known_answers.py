@@ -118,3 +118,20 @@ def test_pmc_traffic_is_keyed_on_the_kernel_source_hash(tmp_path, monkeypatch):
     h1 = srchash.csrc_hash()
     (tmp_path / "a.hip").write_text("y")
     assert srchash.csrc_hash() != h1
+
+
+def test_the_bench_lines_roofline_block_is_the_survey_8d_figure():
+    """`roofline.achieved` = SURVEY 8d's algorithmic bytes / the kernel's time; the structure-exploiting block is
+    the only place where moved bytes are divided, and it says so and carries no key named `frac`"""
+    from sparsebench_amd.bench import line
+    alg = 706234368.0  # SURVEY.md section 8d: Sell-64-1 at HPCG 128^3
+    r = line.roofline_block("spmv_scs64", alg, alg, 118.97, 20, 708425670.0, "profiles/r04_pmc_traffic.json", None)
+    assert r["kernel"] == "spmv_scs64" and r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["achieved"] - alg / 118.97e-6 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12 and 0.74 < r["frac"] < 0.75
+    assert abs(r["traffic_over_bytes"] - 1.0031) < 1e-3 and "algorithmic" in r["bytes_are"]
+    m = line.roofline_block("spmv_prog_fusep", 123272448.0, 790120448.0, 28.6, 20, None, None, "x", on_moved_bytes=True)
+    assert "moved" in m["bytes_are"] and m["bytes_per_launch"] < m["algorithmic_bytes_per_launch"]
+    # CG iteration of the reference's unfused op list (SURVEY 8d): 96 B/row + the SpMV's bytes -> 8 815 it/s at 8 TB/s
+    nr = 128 ** 3
+    assert 96.0 * nr + alg == 907560960.0 and abs(8e12 / (96.0 * nr + alg) - 8814.8) < 0.1
+    assert line.vector_bytes(nr) == 64.0 * nr + 16.0 * nr / 256.0 and line.kernel_name("crs", 0) == "spmv_crs_split" and line.kernel_name("scs", 0) == "spmv_scs64"
