@@ -259,3 +259,16 @@ def test_irregular_workload_line(gpu):
     assert d["preflight"]["ok"] and len(d["preflight"]["checks"]) == 3
     assert all(c["ok"] and c["max_rel_deviation_from_the_reference_history"] <= 1e-12 for c in d["preflight"]["checks"])
     check_fractions(d)
+
+
+def test_the_benchmark_size_line_says_what_the_placement_tuner_saw(gpu):
+    """at the benchmark's own size the upload chooses by measurement which device memory the streamed arrays and the loop's vectors
+    occupy; the line carries what that search saw, and the kernel `value` is quoted on is the reference-layout one"""
+    d, _ = run_bench("--n", "128", "--steps", "10", "--warmup", "3", "--no-cpu", "--loops", "reference", "--passes", "clean,events",
+                     "--sustained-steps", "0")
+    pl = d["config"]["placement"]
+    assert pl and pl["probes_timed"] >= 3 and pl["us_kept"] <= pl["us_first_pair"] <= pl["us_slowest"] * 1.0001
+    assert d["config"]["spmv_kernel"] == "spmv_scs64" and d["roofline"]["kernel"] == "spmv_scs64" and "structure_exploiting" not in d
+    assert d["roofline"]["bytes_per_launch"] == 706234368.0 and 0.55 < d["roofline"]["frac"] <= 0.80  # SURVEY 8d bytes; HBM-bound
+    assert d["preflight"]["ok"] and [c["golden"] for c in d["preflight"]["checks"] if "bench bricks" in c["case"]] == ["hpcg128_x1_scs_C64_sigma256"]
+    check_fractions(d)
