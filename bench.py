@@ -42,8 +42,9 @@ JSON line.
                  every format within 1e-12, CRS and Sell-64-1 identical bits.)
   rccl_only    = (N > 1) the same K steps timed with the peer-mapped paths switched off
                  (sb_comm_data_plane(0): RCCL all-reduce + send/recv), so one invocation yields both curves.
-  sustained    = the same clean loop over 4800 steps in one go (informational: a K = 20 window is 1 ms of GPU work between
-                 host-side pauses, and the rate of a long run is a few per cent higher; `value` stays the K-step figure).
+  sustained    = the same clean loop over 4800 steps in one go, run before the K-step windows (informational; `value` stays the
+                 K-step figure): after idle time the device runs the loop ~5 % slower for its first 50-150 ms under load, on
+                 fixed memory (profiles/r04_placement_lab9.txt); this leg absorbs that.
   phases_us    = per-kernel breakdown of a loop body from an event after every launch (a separate pass).
   K < 100      : the K-step timing is repeated and the MEDIAN is reported (timed_repeats).
   ok           = false when the line is a degraded one (below) or a pre-flight failure.

@@ -339,6 +339,8 @@ double sb_cg_loop_ms(const sb_cg* s);
  * layer's stream; sb_cg_spmv_ms returns their summed duration and count */
 void sb_cg_spmv_timing(sb_cg* s, int on);
 double sb_cg_spmv_ms(sb_cg* s, int* launches);
+/* lab call: the same launches one by one (microseconds each); returns their number, writes at most cap */
+int sb_cg_spmv_us_series(sb_cg* s, float* out, int cap);
 /* per-kernel breakdown of the loop: an event after every launch of a loop body.  sb_cg_phase_ms returns the number
  * of phases P <= 8 and fills ms_out[i] / count_out[i] (summed milliseconds, occurrences) since timing was switched on:
  * 0 p update (+ owed x update), 1 halo (push kernel, or pack + send/recv), 2 SpMV (+ fused p.Ap partials; with the

@@ -260,8 +260,10 @@ def run(ctx, cpu):
         if d.get("t_sus"):
             ks = a.sustained_steps
             out["sustained"] = {"steps": ks, "value": world * ks / d["t_sus"], "ms_per_step": 1e3 * d["t_sus"] / ks,
-                                "note": "the same loop, clean, over %d steps in one go (informational; `value` is the K-step figure the "
-                                        "contract asks for): a window of K = %d steps is a short burst between host-side pauses" % (ks, K)}
+                                "note": "the same loop, clean, over %d steps in one go, run BEFORE the K-step windows (informational; `value` is "
+                                        "the K = %d figure the contract asks for): after idle time the device runs the loop ~5 %% slower "
+                                        "for its first 50-150 ms under load, on fixed memory (profiles/r04_placement_lab9.txt); this leg "
+                                        "absorbs that, the windows after it see the device as a solve of hundreds of iterations does" % (ks, K)}
         if se_mode is not None and se_mode in res and se_mode != primary:
             se = se_block(res[se_mode])
             out["structure_exploiting"] = se

@@ -26,7 +26,7 @@ SYMBOLS = [
     "sb_cg_free", "sb_cg_set_fused", "sb_cg_set_graph", "sb_cg_solve", "sb_cg_run_iters",
     "sb_cg_history", "sb_cg_solution", "sb_cg_check_residual", "sb_cg_region_ms", "sb_version",
     "sb_comm_allgather_bytes", "sb_comm_alltoallv_ints", "sb_comm_barrier", "sb_cg_loop_ms",
-    "sb_cg_spmv_timing", "sb_cg_spmv_ms", "sb_cg_counters", "sb_debug_stream_read_gbs",
+    "sb_cg_spmv_timing", "sb_cg_spmv_ms", "sb_cg_spmv_us_series", "sb_cg_counters", "sb_debug_stream_read_gbs",
     "sb_matrix_pack_level", "sb_set_external_ids", "sb_spmv_native_dot", "sb_matrix_use_packed", "sb_matrix_stream_bytes",
     "sb_matrix_packed_mode", "sb_matrix_crs_kernel", "sb_matrix_lds_window", "sb_matrix_pattern_classes", "sb_matrix_row_patterns", "sb_matrix_row_programs", "sb_comm_p2p_handle", "sb_comm_p2p_open", "sb_comm_p2p_enabled", "sb_halo_p2p_enabled", "sb_cg_start", "sb_cg_finish", "sb_cg_vector_phase", "sb_cg_launches_per_body",
     "sb_comm_init_transport", "sb_comm_p2p_reason", "sb_halo_p2p_reason",
@@ -116,6 +116,7 @@ def load():
         "sb_cg_loop_ms": (C.c_double, [vp]),
         "sb_cg_spmv_timing": (None, [vp, C.c_int]),
         "sb_cg_spmv_ms": (C.c_double, [vp, C.POINTER(C.c_int)]),
+        "sb_cg_spmv_us_series": (C.c_int, [vp, C.POINTER(C.c_float), C.c_int]),
         "sb_cg_counters": (None, [vp, vp]),
         "sb_debug_stream_read_gbs": (C.c_double, [C.c_size_t, C.c_int]),
         "sb_matrix_pack_level": (C.c_int, [vp]),

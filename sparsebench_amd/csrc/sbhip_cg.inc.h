@@ -383,6 +383,21 @@ double sb_cg_spmv_ms(sb_cg* s, int* launches)
   return total;
 }
 
+// lab call (tools/placement_lab11.py): the event-bracketed SpMV launches since sb_cg_spmv_timing(s, 1), one by one (us); returns
+// how many there are (at most `cap` are written)
+int sb_cg_spmv_us_series(sb_cg* s, float* out, int cap)
+{
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  int n = 0;
+  for (size_t i = 0; i + 1 < s->spmvEvUsed; i += 2, n++) {
+    if (n >= cap) continue;
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, s->spmvEv[i], s->spmvEv[i + 1]));
+    out[n] = 1e3f * ms;
+  }
+  return n;
+}
+
 void sb_cg_phase_timing(sb_cg* s, int on)
 {
   s->phaseTiming = on != 0;

@@ -376,20 +376,23 @@ double sb_ddot(uint32_t n, const double* x, const double* y)
 // interact (profiles/r04_placement_lab*.txt) -- while the position INSIDE an allocation changes nothing (289 offsets:
 // 126.7-128.7 us).  Nothing a process can see (address, size, alignment) tells the kinds apart, so the upload MEASURES, with a
 // proxy of the loop body on the loop's own vector layout (p = r + 0.5 p | Ap = A p | r = r - 1e-3 Ap: no scalars, no
-// communication), in up to SB_PLACE_ROUNDS (6) rounds: SB_PLACE_VEC_TRIES (10) fresh allocations of the vectors' arena, each
-// followed by a 700 MB spacer (a pair's speed follows how far apart and where its two allocations lie -- within ~2.5 GB of each
-// other: the slow kind; every pair of 8 stream x 16 arena allocations of a process: profiles/r04_placement_lab7.txt), with the
-// stream in the home it has, then the stream copied into SB_PLACE_TRIES (4) fresh slabs with the best arena; everything tried
-// stays allocated until the end (so that the next try lands further on); the search ends once the pair kept is >= 14.5 % faster than the slowest pair seen
-// (pairs come in levels -- 131 | 137-139 | 143 | 147 | 153-157 us per proxy step at HPCG 128^3 -- in long runs along the allocation
-// order, with the stream fixed as with the arena fixed; pairs whose allocations lie within ~2.5 GB of each other are of the slowest) or after three rounds in a row without
-// anything better (some devices of the pool have no fast pairs at all: 48 probes between 151 and 156 us).  Physically contiguous allocations (hipDeviceMallocContiguous) and power-of-two sizes (one aligned buddy block per buffer) behave
-// the same, and stream + vectors at 256 position pairs inside ONE 48 GiB allocation are all of the slow kind: it is neither
-// fragmentation nor page-table fragment size, and it needs two allocations (profiles/r04_placement_probe_sequences.txt,
-// r04_placement_lab6.txt).  The mechanism is not understood.  The fastest pair is kept -- the arena stays with the matrix and
-// the next sb_cg_create takes its vectors from it -- the rest is freed.  40-120 ms per upload and, for a moment, up to ROUNDS x
-// TRIES x the stream's size (bounded by the memory that is free).  SB_PLACE=0 switches it off; streams below 64 MB
-// (cache resident) are left alone.  Same bytes, same kernels, same arithmetic: same bits.
+// communication), in up to SB_PLACE_ROUNDS (6) rounds:
+//   - SB_PLACE_VEC_TRIES (10) fresh allocations of the vectors' arena, each followed by a 700 MB spacer (pairs whose two
+//     allocations lie within ~2.5 GB of each other are of the slowest kind), timed with the stream in the home it has;
+//   - the stream copied into SB_PLACE_TRIES (4) fresh slabs, each timed with up to four arenas (the best so far, the newest, two
+//     older ones): the level is a table over where BOTH allocations lie (every pair of 8 stream x 16 arena allocations of one
+//     process: profiles/r04_placement_lab7.txt), so a new home for the stream may want another arena.
+// Everything tried stays allocated until the end (the next try lands further on).  Pairs come in levels -- 131 | 137-139 | 143 |
+// 147 | 153-157 us per proxy step at HPCG 128^3 -- in long runs along the allocation order.  The search ends once the pair kept is
+// >= 14.5 % faster than the slowest pair seen or moves the proxy step's algorithmic bytes at >= 6.0 TB/s (the fast level), after
+// three rounds in a row without anything better, or after two rounds within 6 % (one device in three of the pool has no fast
+// pairs at all: 48 probes between 151 and 156 us).  Physically contiguous allocations (hipDeviceMallocContiguous) and
+// power-of-two sizes behave the same, and stream + vectors at 256 position pairs inside ONE 48 GiB allocation are all of the
+// slow kind: it is neither fragmentation nor page-table fragment size, and it needs two allocations
+// (profiles/r04_placement_probe_sequences.txt, r04_placement_lab6.txt).  The mechanism is not understood.  The fastest pair is
+// kept -- the arena stays with the matrix and the next sb_cg_create takes its vectors from it -- the rest is freed.  40-250 ms per
+// upload and, for a moment, up to a quarter of the device's memory (less where less is free).  SB_PLACE=0 switches it off;
+// streams below 64 MB (cache resident) are left alone.  Same bytes, same kernels, same arithmetic: same bits.
 struct VecLayout {
   size_t r, Ap, x, b, p, p2, xexact, total;
 };
@@ -473,6 +476,10 @@ static void tune_matrix_placement(sb_matrix* m)
     m->colInd = sl ? reinterpret_cast<uint32_t*>(sl) : col0, m->val = sl ? reinterpret_cast<double*>(sl + colRegion) : val0;
   };
   int idle = 0; // consecutive rounds that found nothing better
+  // the search is over once the pair kept is >= 14.5 % faster than the slowest pair seen, or moves the proxy step's algorithmic
+  // bytes at 6.0 TB/s (the fast level everywhere it has been seen: 131-133 us at HPCG 128^3 = 6.1 TB/s; the next level is 5.9)
+  const float tFastEnough = (float)(1e6 * (sb_matrix_spmv_bytes(m) + 48.0 * m->nr) / 6.0e12);
+  auto found = [&]() { return tBest <= 0.855f * tWorst || tBest <= tFastEnough; };
   for (int round = 0; round < rounds; round++) {
     const float tBefore = tBest;
     // the vectors' arena, stream in the home it has now
@@ -494,6 +501,7 @@ static void tune_matrix_placement(sb_matrix* m)
       if (verbose > 1) fprintf(stderr, "sbhip placement: round %d arena %d (%p): %.2f us\n", round, k, (void*)q, t);
       tWorst = std::max(tWorst, t);
       if (t < tBest * (arena ? 0.985f : 1.0f)) tBest = t, arena = q; // (a new home has to be worth it: 1.5 %)
+      if (found()) break;
     }
     if (!arena) break;
     // the stream in fresh slabs, best arena
@@ -504,14 +512,24 @@ static void tune_matrix_placement(sb_matrix* m)
       HIP_CHECK(hipMemcpy(sl, col0, colBytes, hipMemcpyDeviceToDevice));
       HIP_CHECK(hipMemcpy(sl + colRegion, val0, valBytes, hipMemcpyDeviceToDevice));
       point_stream(sl);
-      const float t = placement_probe(m, arena, L, ea, eb);
-      timed++;
-      if (verbose > 1) fprintf(stderr, "sbhip placement: round %d slab %d (%p): %.2f us\n", round, k, (void*)sl, t);
-      tWorst = std::max(tWorst, t);
-      if (t < tBest * 0.985f) tBest = t, home = sl;
+      // a new home for the stream is judged with several arenas, not only the best so far: which arena suits a stream depends
+      // on where BOTH lie (profiles/r04_placement_lab7.txt: the level is a table over the two allocations' regions)
+      char* const before = arena;
+      char* partners[4] = { before, arenas.back(), arenas[arenas.size() / 2], arenas[arenas.size() / 4] };
+      for (int a = 0; a < 4; a++) {
+        bool dup = false;
+        for (int b2 = 0; b2 < a; b2++) dup = dup || partners[b2] == partners[a];
+        if (dup) continue;
+        const float t = placement_probe(m, partners[a], L, ea, eb);
+        timed++;
+        tWorst = std::max(tWorst, t);
+        if (verbose > 1) fprintf(stderr, "sbhip placement: round %d slab %d (%p) partner %d (%p): %.2f us\n", round, k, (void*)sl, a, (void*)partners[a], t);
+        if (t < tBest * 0.985f) tBest = t, home = sl, arena = partners[a];
+      }
       point_stream(home);
+      if (found()) break; // (no need for the remaining slabs)
     }
-    if (tBest <= 0.855f * tWorst) break; // the whole range has been seen and the pair kept is at its fast end (levels at HPCG 128^3: 131 | 137-139 | 143 | 147 | 153-157 us)
+    if (found()) break; // the pair kept is at the fast end (levels at HPCG 128^3: 131 | 137-139 | 143 | 147 | 153-157 us)
     idle = (round > 0 && tBest > tBefore * 0.985f) ? idle + 1 : 0;
     if (idle >= 3) break; // three rounds in a row without anything better: this device has nothing faster to offer
     if (round >= 1 && tWorst <= 1.06f * tBest) break; // two rounds (28 pairs over ~20 GB) within 6 %: a device without the fast kind (one in three of the pool)
