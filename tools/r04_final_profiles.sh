@@ -1,30 +1,16 @@
 #!/usr/bin/env bash
 # Round-4 profile set (run on the GPU box from the repo root; results under gpurun_out/r04/, condensed into profiles/ by
 # tools/r04_condense_profiles.sh in the build container):
-#   bench lines (N = 1: configs[2] with the default step count and as the driver types it, configs[1], sigma = 1, CRS, 256^3,
-#   configs[4] stand-in), rocprofv3 --kernel-trace --stats of the CLEAN loop of each kind (`--loops reference` = exactly what
-#   `value` is quoted on; `--loops structure`), and the PMC passes (tools/prof_run.sh: one counter group per run).
+#   PMC passes first (tools/prof_run.sh: one counter group per run) and the traffic file made from them on the box, then the bench
+#   lines as fresh processes (N = 1: configs[2] with the default step count and as the driver types it, configs[1], sigma = 1,
+#   CRS, 256^3, configs[4] stand-in), then rocprofv3 --kernel-trace --stats of the CLEAN loop of each kind
+#   (tools/r04_clean_traces.sh: `--loops reference` = exactly what `value` is quoted on; `--loops structure`).
 set -o pipefail
 O=gpurun_out/r04
 mkdir -p $O gpurun_out/prof
 python3 -c "from sparsebench_amd import srchash; print(srchash.csrc_hash())" > $O/source_hash.txt
 b() { local name=$1; shift; python3 bench.py "$@" > $O/r04_bench_$name.json 2>> $O/bench.err; echo "bench $name rc=$?"; }
-b n1_128_scs_sigma256
-b n1_as_the_driver_types_it --gpus 1 --steps 20 --warmup 5
-b n1_128_scs_sigma1 --sigma 1 --no-cpu
-b n1_64_scs_sigma1 --n 64 --sigma 1
-b n1_256_scs_sigma256 --n 256 --steps 40 --warmup 5 --no-cpu
-b n1_128_crs --fmt crs --no-cpu
-b irregular --workload irregular --irr-sigmas 1,256 --steps 120
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
-for spec in "reference:--loops reference" "structure:--loops structure"; do
-  tag=${spec%%:*}; extra=${spec#*:}
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/r04_clean_$tag -o r1 -- python3 bench.py --no-cpu --steps 240 --no-preflight --passes clean --sustained-steps 0 $extra > gpurun_out/prof/r04_clean_$tag.json 2> gpurun_out/prof/r04_clean_$tag.err || echo "clean trace $tag failed"
-  f=$(find gpurun_out/prof/r04_clean_$tag -name "*kernel_stats.csv" | head -1); cp "$f" $O/r04_clean_${tag}_kernel_stats.csv
-  t=$(find gpurun_out/prof/r04_clean_$tag -name "*kernel_trace.csv" | head -1); python3 tools/scalar_anatomy.py trace "$t" > $O/r04_clean_${tag}_trace_summary.txt
-  cp gpurun_out/prof/r04_clean_$tag.json $O/r04_clean_${tag}_bench_line.json
-  rm -rf gpurun_out/prof/r04_clean_$tag
-done
 # PMC passes of the default bench (both loops: spmv_scs64 and spmv_prog_fusep in one process)
 tools/prof_run.sh r04_hpcg128 bench.py --no-cpu --steps 60 --warmup 5 --no-preflight --sustained-steps 0
 # the native CRS kernel inside CG, and the irregular stand-in: kernel trace + FETCH / WRITE passes + the size split of the memory-side reads
@@ -48,4 +34,23 @@ print("irregular stand-in, spmv_crs_split, memory-side read requests per launch 
 for k, v in sorted(agg.items()):
     v = sorted(v); print("  %-28s %.4g" % (k, v[len(v) // 2]))
 PY
+# HBM bytes per launch from those passes -> profiles/r04_pmc_traffic.json ON THE BOX, so that the bench lines below (fresh processes)
+# find a traffic figure measured with the very kernel sources they run
+python3 tools/make_pmc_traffic.py r04 "sbhip 0.5" hash=$(cat $O/source_hash.txt) r04_hpcg128=hpcg_27pt_128^3_per_gpu_scs_C64_sigma256 r04_hpcg128_crs=hpcg_27pt_128^3_per_gpu_crs_C64_sigma256 r04_irregular=irregular_fe_80^3_nodes_crs > /dev/null
+python3 - <<'PY'
+import json
+p = "profiles/r04_pmc_traffic.json"
+d = json.load(open(p))
+d.get("irregular_fe_80^3_nodes_crs", {}).pop("spmv_scs64", None)  # (launches of both sigmas averaged together: not a per-workload figure)
+json.dump(d, open(p, "w"), indent=1)
+PY
+cp profiles/r04_pmc_traffic.json $O/r04_pmc_traffic.json
+b n1_128_scs_sigma256
+b n1_as_the_driver_types_it --gpus 1 --steps 20 --warmup 5
+b n1_128_scs_sigma1 --sigma 1 --no-cpu
+b n1_64_scs_sigma1 --n 64 --sigma 1
+b n1_256_scs_sigma256 --n 256 --steps 40 --warmup 5 --no-cpu
+b n1_128_crs --fmt crs --no-cpu
+b irregular --workload irregular --irr-sigmas 1,256 --steps 120
+bash tools/r04_clean_traces.sh
 echo done
