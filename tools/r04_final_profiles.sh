@@ -36,6 +36,9 @@ for k, v in sorted(agg.items()):
 PY
 # HBM bytes per launch from those passes -> profiles/r04_pmc_traffic.json ON THE BOX, so that the bench lines below (fresh processes)
 # find a traffic figure measured with the very kernel sources they run
+python3 tools/summarize_prof2.py r04_hpcg128 > $O/r04_hpcg128_pmc_summary.txt
+python3 tools/summarize_prof2.py r04_hpcg128_crs spmv > $O/r04_hpcg128_crs_native_pmc_summary.txt
+python3 tools/summarize_prof2.py r04_irregular spmv > $O/r04_irregular_pmc_summary.txt
 python3 tools/make_pmc_traffic.py r04 "sbhip 0.5" hash=$(cat $O/source_hash.txt) r04_hpcg128=hpcg_27pt_128^3_per_gpu_scs_C64_sigma256 r04_hpcg128_crs=hpcg_27pt_128^3_per_gpu_crs_C64_sigma256 r04_irregular=irregular_fe_80^3_nodes_crs > /dev/null
 python3 - <<'PY'
 import json
