@@ -381,7 +381,9 @@ double sb_ddot(uint32_t n, const double* x, const double* y)
 //     allocations lie within ~2.5 GB of each other are of the slowest kind), timed with the stream in the home it has;
 //   - the stream copied into SB_PLACE_TRIES (4) fresh slabs, each timed with up to four arenas (the best so far, the newest, two
 //     older ones): the level is a table over where BOTH allocations lie (every pair of 8 stream x 16 arena allocations of one
-//     process: profiles/r04_placement_lab7.txt), so a new home for the stream may want another arena.
+//     process: profiles/r04_placement_lab7.txt), so a new home for the stream may want another arena.  The first slab of the
+//     first round is MANAGED memory preferred on and prefetched to this device (SB_PLACE_MANAGED=0: not): wherever the home
+//     stream was slow with every plain arena, that slab was fast with every one of them (profiles/r04_placement_lab12.txt).
 // Everything tried stays allocated until the end (the next try lands further on).  Pairs come in levels -- 131 | 137-139 | 143 |
 // 147 | 153-157 us per proxy step at HPCG 128^3 -- in long runs along the allocation order.  The search ends once the pair kept is
 // >= 14.5 % faster than the slowest pair seen or moves the proxy step's algorithmic bytes at >= 6.0 TB/s (the fast level), or after
@@ -478,6 +480,7 @@ static void tune_matrix_placement(sb_matrix* m)
   int idle = 0; // consecutive rounds that found nothing better
   // no early exit for a device that looks flat: one process in four on devices that DO have fast pairs sees its first 52 pairs
   // within 5 % and finds a fast one among the next 50 (profiles/r04_placement_tuner_runs.txt)
+  const bool managedFirst = !(getenv("SB_PLACE_MANAGED") && atoi(getenv("SB_PLACE_MANAGED")) == 0);
   const float flat = getenv("SB_PLACE_FLAT") ? (float)atof(getenv("SB_PLACE_FLAT")) : 0.f;
   // the search is over once the pair kept is >= 14.5 % faster than the slowest pair seen, or moves the proxy step's algorithmic
   // bytes at 6.0 TB/s (the fast level everywhere it has been seen: 131-133 us at HPCG 128^3 = 6.1 TB/s; the next level is 5.9)
@@ -506,11 +509,26 @@ static void tune_matrix_placement(sb_matrix* m)
       if (t < tBest * (arena ? 0.985f : 1.0f)) tBest = t, arena = q; // (a new home has to be worth it: 1.5 %)
       if (found()) break;
     }
-    if (!arena) break;
-    // the stream in fresh slabs, best arena
-    for (int k = 0; k < tries && room(slabBytes); k++) {
+    if (!arena || found()) break;
+    // the stream in fresh slabs
+    for (int k = (round == 0 && managedFirst ? -1 : 0); k < tries && room(slabBytes); k++) {
       char* sl = nullptr;
-      if (hipMalloc(&sl, slabBytes) != hipSuccess) { (void)hipGetLastError(); break; }
+      if (k < 0) {
+        // the first candidate of all: MANAGED memory whose preferred location is this device, prefetched to it.  With the vectors
+        // in plain hipMalloc memory such a stream ran at the fast level with every one of 8 arenas in 6 of 6 processes on devices
+        // that have one (profiles/r04_placement_lab12.txt: 131-134 us where plain, uncached, fine-grained and contiguous slabs
+        // allocated at the same moment gave 145-155); the vectors in managed memory are of the slow kind with any stream.  Where
+        // managed memory is not device memory (no HMM), or on a device without fast pairs, the probe says so and it is dropped.
+        if (hipMallocManaged((void**)&sl, slabBytes, hipMemAttachGlobal) != hipSuccess) { (void)hipGetLastError(); held -= slabBytes; continue; }
+        if (hipMemAdvise(sl, slabBytes, hipMemAdviseSetPreferredLocation, g.device) != hipSuccess
+            || hipMemPrefetchAsync(sl, slabBytes, g.device, g.stream) != hipSuccess
+            || hipStreamSynchronize(g.stream) != hipSuccess) {
+          (void)hipGetLastError();
+          (void)hipFree(sl);
+          held -= slabBytes;
+          continue;
+        }
+      } else if (hipMalloc(&sl, slabBytes) != hipSuccess) { (void)hipGetLastError(); break; }
       slabs.push_back(sl);
       HIP_CHECK(hipMemcpy(sl, col0, colBytes, hipMemcpyDeviceToDevice));
       HIP_CHECK(hipMemcpy(sl + colRegion, val0, valBytes, hipMemcpyDeviceToDevice));
