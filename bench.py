@@ -42,6 +42,8 @@ JSON line.
                  every format within 1e-12, CRS and Sell-64-1 identical bits.)
   rccl_only    = (N > 1) the same K steps timed with the peer-mapped paths switched off
                  (sb_comm_data_plane(0): RCCL all-reduce + send/recv), so one invocation yields both curves.
+  roofline.device_stream_read_GBs / achieved_over_device_stream_read = (N = 1, informational) a plain streaming read of a fresh
+                 1 GiB buffer measured in the same process after the timed passes, and the SpMV's rate as a fraction of it.
   sustained    = the same clean loop over 4800 steps in one go, run before the K-step windows (informational; `value` stays the
                  K-step figure): after idle time the device runs the loop ~5 % slower for its first 50-150 ms under load, on
                  fixed memory (profiles/r04_placement_lab9.txt); this leg absorbs that.

@@ -205,6 +205,12 @@ def run(ctx, cpu):
         else:
             roof["note"] = ("the SpMV streams the reference's own %s arrays (12 B per stored element): bytes = SURVEY 8d's algorithmic "
                             "figure, no use of the matrix's structure" % ("CRS" if a.fmt == "crs" else "Sell-C-sigma"))
+        if world == 1 and roof["achieved"] > 0:
+            # informational: what THIS device streams (a plain read of a fresh 1 GiB buffer, best of three allocations) next to the
+            # 8 TB/s of the data sheet that `frac` is taken against -- measured after all timed passes
+            stream = max(L.sb_debug_stream_read_gbs(1 << 30, 20) for _ in range(3))
+            roof["device_stream_read_GBs"] = stream
+            roof["achieved_over_device_stream_read"] = roof["achieved"] / stream
         out = {
             "metric": "cg_iterations_per_s",
             "value": world * it_s,

@@ -270,5 +270,7 @@ def test_the_benchmark_size_line_says_what_the_placement_tuner_saw(gpu):
     assert pl and pl["probes_timed"] >= 3 and pl["us_kept"] <= pl["us_first_pair"] <= pl["us_slowest"] * 1.0001
     assert d["config"]["spmv_kernel"] == "spmv_scs64" and d["roofline"]["kernel"] == "spmv_scs64" and "structure_exploiting" not in d
     assert d["roofline"]["bytes_per_launch"] == 706234368.0 and 0.55 < d["roofline"]["frac"] <= 0.80  # SURVEY 8d bytes; HBM-bound
+    # (informational, beside the data-sheet peak: what this device streams, measured in the same process)
+    assert 4000 < d["roofline"]["device_stream_read_GBs"] < 8000 and 0.6 < d["roofline"]["achieved_over_device_stream_read"] < 1.05
     assert d["preflight"]["ok"] and [c["golden"] for c in d["preflight"]["checks"] if "bench bricks" in c["case"]] == ["hpcg128_x1_scs_C64_sigma256"]
     check_fractions(d)

@@ -7,6 +7,9 @@ r = d.get("roofline")
 if r:
     print("roofline: %-18s %7.2f us  %7.1f MB  %6.0f GB/s  frac %.3f  traffic %s" % (
         r["kernel"], r["avg_launch_us"], r["bytes_per_launch"] / 1e6, r["achieved"], r["frac"], r.get("traffic")))
+    if r.get("device_stream_read_GBs"):
+        print("          this device streams %.0f GB/s (plain read, 1 GiB): the kernel is at %.3f of that" % (
+            r["device_stream_read_GBs"], r["achieved_over_device_stream_read"]))
 for k in ("cg_frac_of_roofline", "cg_frac_of_hbm_peak_on_moved_bytes"):
     if d.get(k) is not None:
         print("%s = %.3f" % (k, d[k]))
