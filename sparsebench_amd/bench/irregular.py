@@ -78,7 +78,8 @@ def run(ctx, cpu):
             "spmv_useful_GBs": ((12.0 * prob.nnzTrue + 16.0 * prob.nr) / (d["spmv_us"] * 1e-6) / 1e9) if d["launches"] else None,
             "separate_dot_pass": dot_pass, "launches_per_iteration": d["launches_per_body"], "phases_us": phase_table(d["phases"]),
             "cg_frac_of_roofline": it * (96.0 * prob.nr + d["alg"]) / 1e9 / HBM_PEAK_GBS,
-            "cg_frac_of_hbm_peak_on_moved_bytes": cg_moved * it / 1e9 / HBM_PEAK_GBS}
+            "cg_frac_of_hbm_peak_on_moved_bytes": cg_moved * it / 1e9 / HBM_PEAK_GBS,
+            "placement": prob.placement_report()}  # what the upload's placement tuner saw
         if best is None or formats[name]["cg_iterations_per_s"] > formats[best]["cg_iterations_per_s"]:
             best = name
             meta = {"rows": prob.nr, "nnz": prob.nnzTrue}
